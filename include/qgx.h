@@ -1,0 +1,173 @@
+/*
+ * qgx.h — C ABI of the MI355X (gfx950) online parameterized-QG ensemble engine.
+ *
+ * Drop-in boundary for ONE hot path of m2lines/pyqg_generative: the per-step work
+ * that `pyqg_generative/tools/simulate.py:109-145` (run_simulation) drives through
+ * `pyqg.QGModel.run_with_snapshots` and the `Parameterization.__call__` plugin
+ * (`pyqg_generative/models/parameterization.py:23-34`).  Each entry point cites the
+ * reference interface it replaces (paths relative to the reference repository;
+ * "pyqg" = pyqg 0.7.2, the un-vendored spectral core the reference calls into).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative qgx_status; nothing throws
+ *     across the ABI; qgx_last_error() gives a thread-local message.
+ *   - all `*_dev` pointers are DEVICE pointers (e.g. torch tensor.data_ptr()),
+ *     caller-owned and kept alive by the caller until `stream` is synchronised.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *     No entry point on the step path synchronises the device.
+ *   - ensemble-batched layouts, C order:
+ *       real fields      (B, 2, N, N)      double   [member][layer][y][x]
+ *       spectral fields  (B, 2, N, N/2+1)  complex double, interleaved (re,im),
+ *                        l index ordered [0..N/2-1, -N/2..-1], k index [0..N/2]
+ *       latent noise z   (B, 2, N, N)      float (GAN/VAE) or double (GZ)
+ *   - one host thread per handle; handles are not thread-safe.
+ */
+#ifndef QGX_H
+#define QGX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum qgx_status {
+    QGX_OK = 0,
+    QGX_ERR_INVALID = -1,     /* bad argument / unsupported size            */
+    QGX_ERR_HIP = -2,         /* a HIP runtime call failed                   */
+    QGX_ERR_STATE = -3,       /* call not valid in the handle's state        */
+    QGX_ERR_NOMEM = -4
+} qgx_status;
+
+/* ---- model ------------------------------------------------------------------
+ * Replaces pyqg.QGModel(**pyqg_params) as constructed at simulate.py:83,121 and
+ * stochastic_pyqg.py:78-79.  Field names and defaults are pyqg's. */
+typedef struct qgx_config {
+    int32_t nx;          /* N = nx = ny; even, N = 2^a 3^b, 8 <= N <= 512             */
+    int32_t n_members;   /* B: ensemble members resident on this device               */
+    int32_t device;      /* HIP device ordinal                                        */
+    int32_t reserved;
+    double  L;           /* domain size [m]                     (pyqg default 1e6)     */
+    double  dt;          /* time step [s]                       (7200)                */
+    double  rek;         /* bottom drag [1/s]                   (5.787e-7)            */
+    double  delta;       /* H1/H2                               (0.25)                */
+    double  beta;        /* [1/(m s)]                           (1.5e-11)             */
+    double  rd;          /* deformation radius [m]              (15000)               */
+    double  U1, U2;      /* background zonal flow [m/s]         (0.025, 0)            */
+    double  H1;          /* upper layer thickness [m]           (500)                 */
+    double  filterfac;   /* exponential filter strength         (23.6)                */
+} qgx_config;
+
+typedef struct qgx_model qgx_model;          /* opaque */
+typedef struct qgx_generator qgx_generator;  /* opaque */
+
+enum qgx_field {               /* pyqg attribute of the same name */
+    QGX_F_Q = 0,      /* m.q      real      */
+    QGX_F_QH = 1,     /* m.qh     spectral  */
+    QGX_F_PH = 2,     /* m.ph     spectral (from the last inversion)            */
+    QGX_F_U = 3,      /* m.u      real     (from the last inversion)            */
+    QGX_F_V = 4,      /* m.v      real                                          */
+    QGX_F_DQHDT = 5,  /* m.dqhdt     spectral (tendency of the last step)       */
+    QGX_F_DQHDT_P = 6,
+    QGX_F_DQHDT_PP = 7,
+    QGX_F_S = 8,      /* real: subgrid forcing used by the last step (m.PV_forcing) */
+    QGX_F_Z = 9       /* latent noise held by the sampler (float or double)     */
+};
+
+enum qgx_table {               /* grid constants, (N, N/2+1) double unless noted */
+    QGX_T_FILTR = 0,  /* m.filtr */
+    QGX_T_WV2 = 1,    /* m.wv2   */
+    QGX_T_A = 2,      /* m.a  (2,2,N,N/2+1) */
+    QGX_T_KK = 3,     /* m.kk (N/2+1)       */
+    QGX_T_LL = 4      /* m.ll (N)           */
+};
+
+int qgx_create(const qgx_config *cfg, qgx_model **out);
+int qgx_destroy(qgx_model *m);
+
+/* m.q = q  (kernel.pyx property q: also refreshes qh = rfft2(q)); call sites
+ * simulate.py:131, operators.py:232; set_q1q2 at simulate.py:167. */
+int qgx_set_q(qgx_model *m, const double *q_dev, void *stream);
+/* m.qh = qh (also refreshes q = irfft2(qh)). */
+int qgx_set_qh(qgx_model *m, const double *qh_dev, void *stream);
+/* copy a state field into a caller buffer of the layout given above */
+int qgx_get(qgx_model *m, int field, void *out_dev, void *stream);
+/* copy a grid constant (host pointer, doubles) */
+int qgx_get_table(qgx_model *m, int table, double *out_host);
+/* bytes of a field for this model (so callers can size buffers) */
+size_t qgx_field_bytes(const qgx_model *m, int field);
+
+/* m._invert(): ph, u, v from qh (simulate.py:132,168; operators.py:233). */
+int qgx_invert(qgx_model *m, void *stream);
+
+/* ---- stepping ----------------------------------------------------------------
+ * Replaces pyqg Model._step_forward driven by run_with_snapshots
+ * (simulate.py:137) including the plugin call of parameterization.py:23-34 and
+ * the samplers of stochastic_pyqg.py:30-72. */
+enum qgx_sampling { QGX_SAMPLING_AR1 = 0, QGX_SAMPLING_CONSTANT = 1 };
+
+typedef struct qgx_param {
+    qgx_generator *gen;      /* NULL: use `forcing_dev` as S (or no forcing if that is NULL too) */
+    int32_t  sampling;       /* qgx_sampling                                             */
+    int32_t  nsteps;         /* decorrelation steps (AR1: <0 freezes the noise)          */
+    double   weight;         /* `model_weight * parameterization` (simulate.py:242)      */
+    uint64_t seed;           /* Philox key for on-device latent noise                    */
+    uint64_t member_offset;  /* global id of member 0 on this device (multi-GPU shards)  */
+    const void *z_external_dev; /* if non-NULL: white noise xi for THIS step, layout of z
+                                   (parity tests); only honoured for nsteps_to_run == 1  */
+    const double *forcing_dev;  /* gen == NULL: externally supplied S (B,2,N,N), used as is
+                                   (plain pyqg q_parameterization semantics)             */
+    int32_t  demean;         /* subtract the per-layer spatial mean of S (parameterization.py:25) */
+    int32_t  reserved;
+} qgx_param;
+
+/* advance `nsteps_to_run` steps; `p` may be NULL (unparameterized, simulate.py:121).
+ * If `refresh_diag` != 0 the last step also stores ph,u,v (as pyqg keeps them). */
+int qgx_step(qgx_model *m, int nsteps_to_run, const qgx_param *p, int refresh_diag, void *stream);
+/* step counter / ablevel (m.tc) and reset of the AB history */
+int64_t qgx_step_count(const qgx_model *m);
+int qgx_reset_time(qgx_model *m);
+
+/* status reductions of pyqg's _print_status: out_dev[2*b+0] = KE, [2*b+1] = CFL */
+int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream);
+
+/* ---- generator ---------------------------------------------------------------
+ * Replaces AndrewCNN inference through apply_function (cnn_tools.py:125-176,
+ * 702-735) for CGANRegression.G / CVAERegression.decoder / MeanVarModel nets. */
+enum qgx_gen_kind { QGX_GEN_GAN = 0, QGX_GEN_VAE = 1, QGX_GEN_GZ = 2 };
+
+typedef struct qgx_cnn_weights {      /* host pointers, float32, PyTorch layouts */
+    int32_t n_in, n_out;              /* 4/2 and 2                                   */
+    const float *conv_w[8];           /* (cout, cin, k, k)                           */
+    const float *conv_b[8];           /* (cout)                                      */
+    const float *bn_gamma[7], *bn_beta[7], *bn_mean[7], *bn_var[7];
+    float bn_eps;                     /* 1e-5                                        */
+} qgx_cnn_weights;
+
+int qgx_generator_create(int kind, const qgx_cnn_weights *nets, int n_nets,
+                         const float x_std[2], const float y_std[2], int device,
+                         qgx_generator **out);
+int qgx_generator_destroy(qgx_generator *g);
+/* S = y_std * G([q/x_std, z]) (cgan_regression.py:157-162; cvae_regression.py:131-136;
+ * mean_var_model.py:105-109).  demean != 0 also applies parameterization.py:25.
+ * z is float for GAN/VAE, double for GZ. */
+int qgx_generator_forward(qgx_generator *g, const double *q_dev, const void *z_dev,
+                          double *S_dev, int B, int N, int demean, void *stream);
+/* raw CNN forward of net `inet`: x (B,n_in,N,N) float -> y (B,n_out,N,N) float
+ * (AndrewCNN.forward in eval mode; used by predict_mean_snapshot / offline sampling) */
+int qgx_cnn_forward(qgx_generator *g, int inet, const float *x_dev, float *y_dev,
+                    int B, int N, void *stream);
+
+/* ---- latent noise ------------------------------------------------------------
+ * z <- a z + b xi with xi ~ N(0,1) from Philox4x32-10 (stochastic_pyqg.py:43-49). */
+int qgx_noise_normal(void *z_dev, int is_double, int B, int n_per_member, uint64_t seed,
+                     uint64_t member_offset, uint64_t step, double a, double b, void *stream);
+
+const char *qgx_last_error(void);
+const char *qgx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QGX_H */

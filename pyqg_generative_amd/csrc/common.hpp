@@ -1,0 +1,108 @@
+// Shared host-side declarations of the qgx engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include <string>
+#include "../../include/qgx.h"
+
+namespace qgx {
+
+void set_error(const char *fmt, ...);
+
+#define QGX_HIP(call)                                                              \
+    do {                                                                           \
+        hipError_t e_ = (call);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            qgx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),  \
+                           __FILE__, __LINE__);                                    \
+            return QGX_ERR_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define QGX_REQUIRE(cond, ...)                                                     \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            qgx::set_error(__VA_ARGS__);                                           \
+            return QGX_ERR_INVALID;                                                \
+        }                                                                          \
+    } while (0)
+
+constexpr int MAX_RADIX_PASSES = 12;
+
+// Device-visible description of one model's grid and constants (passed by value).
+struct SpecDev {
+    int N, NK, LD, B;
+    int nrad;
+    int rad[MAX_RADIX_PASSES];      // DIF pass radices, product = N
+    const double *filtr, *wv2, *a;  // a: 4 tables of N*NK (a00,a01,a10,a11)
+    const double *kk, *ll;
+    const double2 *tw;              // tw[t] = exp(-2 pi i t / N)
+    const int *pos;                 // pos[freq] -> position after the DIF passes
+    double U[2], Qy[2];
+    double rek, invN2, dt, dx;
+    double H[2], Htot;
+};
+
+// Arguments of one time step (spectral_small.hip / spectral_large.hip).
+struct StepArgs {
+    const double2 *qh_in;   // (B,2,N,NK)
+    double2 *qh_out;
+    double *q;              // (B,2,N,N) in: q^n, out: q^{n+1}
+    const double *S;        // (B,2,N,N) or null
+    double2 *dqh;           // spectral forcing of this step (pyqg m.dqh)
+    double2 *dq_new;        // newest tendency (overwrites the oldest history slot)
+    const double2 *dq_p, *dq_pp;
+    double2 *ph;            // diagnostics (written when diag != 0)
+    double *u, *v;
+    double dt1, dt2, dt3;
+    double weight;
+    int has_S, demean, diag;
+};
+
+}  // namespace qgx
+
+struct qgx_generator;
+
+struct qgx_model {
+    qgx_config cfg;
+    qgx::SpecDev d;
+    int N, NK, B;
+    bool small;                     // whole member field fits one CU's LDS
+    // tables (device) + host copies for qgx_get_table
+    double *t_filtr = nullptr, *t_wv2 = nullptr, *t_a = nullptr, *t_kk = nullptr, *t_ll = nullptr;
+    double2 *t_tw = nullptr;
+    int *t_pos = nullptr;
+    std::vector<double> h_filtr, h_wv2, h_a, h_kk, h_ll;
+    // state (device)
+    double *q = nullptr, *u = nullptr, *v = nullptr, *S = nullptr;
+    double2 *qh[2] = {nullptr, nullptr};   // ping-pong; qh[cur_q] is current
+    double2 *ph = nullptr, *dqh = nullptr; // dqh: spectral forcing of the last step (pyqg m.dqh)
+    double2 *dq[3] = {nullptr, nullptr, nullptr};
+    double2 *zbuf = nullptr;               // large-N path: (B,2,N,N) complex work array
+    int cur_q = 0;
+    int i_new = 0, i_p = 1, i_pp = 2;      // roles of dq[]
+    void *z = nullptr;                     // latent noise (B,2,N,N) float or double
+    void *xi = nullptr;                    // scratch white noise for AR1
+    bool z_double = false;
+    bool have_noise = false;
+    int64_t const_counter = 0;
+    bool have_forcing = false;
+    int64_t tc = 0;
+    int ablevel = 0;
+    uint64_t noise_step = 0;
+};
+
+namespace qgx {
+// generator entry used by the stepper (conv.hip)
+int generator_forward(qgx_generator *g, const double *q, const void *z, double *S, int B, int N,
+                      int demean, hipStream_t st);
+bool generator_noise_is_double(const qgx_generator *g);
+int noise_update(void *z, const void *xi_ext, bool is_double, int B, int n_per_member, uint64_t seed,
+                 uint64_t member_offset, uint64_t step, double a, double b, hipStream_t st);
+int noise_normal(void *z, bool is_double, int B, int n_per_member, uint64_t seed,
+                 uint64_t member_offset, uint64_t step, double a, double b, hipStream_t st);
+}  // namespace qgx

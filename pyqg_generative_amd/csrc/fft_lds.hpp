@@ -1,0 +1,133 @@
+// In-LDS mixed-radix complex FFT passes (float64) for gfx950.
+//
+// Forward transform = decimation-in-frequency, in place, natural order in ->
+// digit-reversed order out.  Inverse = the transposed flow graph
+// (decimation-in-time, conjugate twiddles), digit-reversed in -> natural out.
+// Spectral-space code addresses coefficients through SpecDev::pos[], so no
+// reordering pass is ever executed.  Radices 2, 3, 4.
+//
+// A "line" is one 1-D transform of length N living in LDS at
+//   base + line * line_stride + e * elem_stride      (units: double2)
+// Work items (line, butterfly) are dealt so that consecutive lanes take
+// consecutive LINES: with the row stride padded to N+1 elements both the row
+// passes (lines = rows, stride N+1) and the column passes (lines = columns,
+// stride 1) are free of LDS bank conflicts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace qgx {
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cmulc(double2 a, double2 b) {  // a * conj(b)
+    return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 cscale(double2 a, double s) { return make_double2(a.x * s, a.y * s); }
+// multiply by -i (forward) / +i (inverse)
+__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }
+__device__ __forceinline__ double2 mul_pi(double2 a) { return make_double2(-a.y, a.x); }
+
+template <int R, bool FWD>
+__device__ __forceinline__ void small_dft(double2 (&v)[R]) {
+    if constexpr (R == 2) {
+        double2 a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    } else if constexpr (R == 4) {
+        double2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
+        double2 s13 = cadd(v[1], v[3]), d13 = csub(v[1], v[3]);
+        double2 r = FWD ? mul_mi(d13) : mul_pi(d13);
+        v[0] = cadd(s02, s13);
+        v[1] = cadd(d02, r);
+        v[2] = csub(s02, s13);
+        v[3] = csub(d02, r);
+    } else {  // R == 3
+        const double c = -0.5, s = 0.86602540378443864676;   // cos, sin of 2 pi / 3
+        double2 t = cadd(v[1], v[2]);
+        double2 d = csub(v[1], v[2]);
+        double2 m = make_double2(v[0].x + c * t.x, v[0].y + c * t.y);
+        // FWD: w = exp(-2 pi i/3): y1 = m - i s d, y2 = m + i s d ; inverse swaps
+        double2 isd = make_double2(-s * d.y, s * d.x);       // i * s * d
+        v[0] = cadd(v[0], t);
+        if (FWD) { v[1] = csub(m, isd); v[2] = cadd(m, isd); }
+        else     { v[1] = cadd(m, isd); v[2] = csub(m, isd); }
+    }
+}
+
+// One pass of radix R with current block size n over `nl` lines.
+template <int R, bool FWD>
+__device__ __forceinline__ void fft_pass(double2 *Z, int nl, int ls, int es, int n, int N,
+                                         const double2 *__restrict__ tw) {
+    const int sub = n / R;
+    const int per_line = N / R;
+    const int total = nl * per_line;
+    const int tstride = N / n;
+    for (int w = threadIdx.x; w < total; w += blockDim.x) {
+        const int bb = w / nl;
+        const int line = w - bb * nl;
+        const int blk = bb / sub;
+        const int b = bb - blk * sub;
+        double2 *base = Z + line * ls + (blk * n + b) * es;
+        const int step = sub * es;
+        double2 v[R];
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[m] = base[m * step];
+        if constexpr (FWD) {
+            small_dft<R, true>(v);
+#pragma unroll
+            for (int m = 1; m < R; ++m) v[m] = cmul(v[m], tw[m * b * tstride]);
+        } else {
+#pragma unroll
+            for (int m = 1; m < R; ++m) v[m] = cmulc(v[m], tw[m * b * tstride]);
+            small_dft<R, false>(v);
+        }
+#pragma unroll
+        for (int m = 0; m < R; ++m) base[m * step] = v[m];
+    }
+}
+
+template <bool FWD>
+__device__ __forceinline__ void fft_pass_any(int R, double2 *Z, int nl, int ls, int es, int n, int N,
+                                             const double2 *__restrict__ tw) {
+    if (R == 4) fft_pass<4, FWD>(Z, nl, ls, es, n, N, tw);
+    else if (R == 2) fft_pass<2, FWD>(Z, nl, ls, es, n, N, tw);
+    else fft_pass<3, FWD>(Z, nl, ls, es, n, N, tw);
+}
+
+// 1-D transforms along `nl` lines; block-wide, ends with a barrier.
+__device__ __forceinline__ void fft_lines_fwd(double2 *Z, int nl, int ls, int es, int N, int nrad,
+                                              const int *rad, const double2 *tw) {
+    int n = N;
+    for (int p = 0; p < nrad; ++p) {
+        fft_pass_any<true>(rad[p], Z, nl, ls, es, n, N, tw);
+        n /= rad[p];
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void fft_lines_inv(double2 *Z, int nl, int ls, int es, int N, int nrad,
+                                              const int *rad, const double2 *tw) {
+    int n = 1;
+    for (int p = nrad - 1; p >= 0; --p) {
+        n *= rad[p];
+        fft_pass_any<false>(rad[p], Z, nl, ls, es, n, N, tw);
+        __syncthreads();
+    }
+}
+
+// full 2-D transforms of an N x N field with row stride LD (callers barrier BEFORE)
+__device__ __forceinline__ void fft2d_fwd(double2 *Z, int N, int LD, int nrad, const int *rad,
+                                          const double2 *tw) {
+    fft_lines_fwd(Z, N, LD, 1, N, nrad, rad, tw);   // along x, lines = rows
+    fft_lines_fwd(Z, N, 1, LD, N, nrad, rad, tw);   // along y, lines = columns
+}
+__device__ __forceinline__ void fft2d_inv(double2 *Z, int N, int LD, int nrad, const int *rad,
+                                          const double2 *tw) {
+    fft_lines_inv(Z, N, 1, LD, N, nrad, rad, tw);
+    fft_lines_inv(Z, N, LD, 1, N, nrad, rad, tw);
+}
+
+}  // namespace qgx

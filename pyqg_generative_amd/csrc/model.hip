@@ -1,0 +1,401 @@
+// Host side of the C ABI for the spectral model: tables, state, stepping loop.
+// Restates pyqg 0.7.2 model.py::{_initialize_grid,_initialize_filter,_step_forward},
+// qg_model.py::{_initialize_background,_initialize_inversion_matrix,_calc_cfl,_calc_ke}
+// (constructed by the reference at pyqg_generative/tools/simulate.py:83,121 and
+// tools/stochastic_pyqg.py:78-88).
+#include "common.hpp"
+#include <cmath>
+#include <new>
+
+namespace qgx {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// spectral_small.hip
+bool small_path_fits(int N);
+int small_prepare(const SpecDev &d);
+int small_step(const SpecDev &d, const StepArgs &a, hipStream_t st);
+int small_q_to_qh(const SpecDev &d, const double *q, double2 *qh, hipStream_t st);
+int small_qh_to_q(const SpecDev &d, const double2 *qh, double *q, hipStream_t st);
+int small_invert(const SpecDev &d, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st);
+// spectral_large.hip
+int large_prepare(const SpecDev &d);
+int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st);
+int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st);
+int large_invert(qgx_model *m, hipStream_t st);
+int large_step(qgx_model *m, const StepArgs &a, hipStream_t st);
+
+// One _step_forward: AB3 coefficient schedule of kernel.pyx::_forward_timestep, history rotation.
+static int model_step_once(qgx_model *m, bool has_S, const double *S, double weight, int demean, int diag,
+                           hipStream_t st) {
+    StepArgs a;
+    const double dt = m->cfg.dt;
+    if (m->ablevel == 0) { a.dt1 = dt; a.dt2 = 0.0; a.dt3 = 0.0; m->ablevel = 1; }
+    else if (m->ablevel == 1) { a.dt1 = 1.5 * dt; a.dt2 = -0.5 * dt; a.dt3 = 0.0; m->ablevel = 2; }
+    else { a.dt1 = 23. / 12. * dt; a.dt2 = -16. / 12. * dt; a.dt3 = 5. / 12. * dt; }
+    // Slots after step n-1: i_new = T_{n-1}, i_p = T_{n-2}, i_pp = dead.  T_n goes to the dead slot.
+    a.qh_in = m->qh[m->cur_q];
+    a.qh_out = m->qh[m->cur_q ^ 1];
+    a.q = m->q;
+    a.S = S;
+    a.dqh = m->dqh;
+    a.dq_new = m->dq[m->i_pp];
+    a.dq_p = m->dq[m->i_new];
+    a.dq_pp = m->dq[m->i_p];
+    a.ph = m->ph; a.u = m->u; a.v = m->v;
+    a.weight = weight;
+    a.has_S = has_S ? 1 : 0; a.demean = demean; a.diag = diag;
+    int rc = m->small ? small_step(m->d, a, st) : large_step(m, a, st);
+    if (rc) return rc;
+    const int dead = m->i_pp;
+    m->i_pp = m->i_p; m->i_p = m->i_new; m->i_new = dead;
+    m->cur_q ^= 1;
+    m->tc += 1;
+    return QGX_OK;
+}
+
+static bool factor_radices(int N, int *rad, int &nrad) {
+    nrad = 0;
+    int n = N;
+    while (n % 4 == 0) { rad[nrad++] = 4; n /= 4; }
+    while (n % 2 == 0) { rad[nrad++] = 2; n /= 2; }
+    while (n % 3 == 0) { rad[nrad++] = 3; n /= 3; }
+    return n == 1 && nrad <= MAX_RADIX_PASSES;
+}
+
+template <class T>
+static int upload(T *&dst, const std::vector<T> &h) {
+    QGX_HIP(hipMalloc((void **)&dst, h.size() * sizeof(T)));
+    QGX_HIP(hipMemcpy(dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return QGX_OK;
+}
+template <class T>
+static int dalloc(T *&dst, size_t n) {
+    QGX_HIP(hipMalloc((void **)&dst, n * sizeof(T)));
+    QGX_HIP(hipMemset(dst, 0, n * sizeof(T)));
+    return QGX_OK;
+}
+
+// ---- status reductions: pyqg model.py::_print_status -> qg_model._calc_ke / _calc_cfl
+__global__ void k_status(SpecDev d, const double2 *ph, const double *u, const double *v, double *out) {
+    __shared__ double s_ke[16], s_mx[16];
+    const int N = d.N, NK = d.NK, b = blockIdx.x;
+    const int sz = N * NK, rz = N * N;
+    const double2 *p = ph + (size_t)b * 2 * sz;
+    double ke = 0.0;
+    for (int idx = threadIdx.x; idx < 2 * sz; idx += blockDim.x) {
+        const int k = idx / sz, r = idx - k * sz;
+        const int i = r % NK;
+        const double2 c = p[idx];
+        double w = 2.0 * d.wv2[r] * (c.x * c.x + c.y * c.y) * d.invN2 * d.invN2;  // 2|wv ph|^2 / M^2
+        if (i == 0 || i == NK - 1) w *= 0.5;
+        ke += 0.5 * d.H[k] * w;
+    }
+    double mx = 0.0;
+    const double *uu = u + (size_t)b * 2 * rz, *vv = v + (size_t)b * 2 * rz;
+    for (int idx = threadIdx.x; idx < 2 * rz; idx += blockDim.x) {
+        const int k = idx / rz;
+        mx = fmax(mx, fmax(fabs(uu[idx] + d.U[k]), fabs(vv[idx])));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        ke += __shfl_down(ke, o);
+        mx = fmax(mx, __shfl_down(mx, o));
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s_ke[wave] = ke; s_mx[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tk = 0, tm = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { tk += s_ke[w]; tm = fmax(tm, s_mx[w]); }
+        out[2 * b] = tk / d.Htot;
+        out[2 * b + 1] = tm * d.dt / d.dx;
+    }
+}
+
+}  // namespace qgx
+
+using namespace qgx;
+
+extern "C" const char *qgx_last_error(void) { return g_err; }
+extern "C" const char *qgx_version(void) { return "qgx 0.1 (gfx950)"; }
+
+extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
+    QGX_REQUIRE(cfg && out, "qgx_create: null argument");
+    const int N = cfg->nx;
+    QGX_REQUIRE(N >= 8 && N <= 512 && N % 2 == 0, "qgx_create: nx=%d unsupported (even, 8..512)", N);
+    QGX_REQUIRE(cfg->n_members >= 1, "qgx_create: n_members must be >= 1");
+    int rad[MAX_RADIX_PASSES], nrad;
+    QGX_REQUIRE(factor_radices(N, rad, nrad), "qgx_create: nx=%d is not of the form 2^a 3^b", N);
+    QGX_HIP(hipSetDevice(cfg->device));
+
+    qgx_model *m = new (std::nothrow) qgx_model();
+    if (!m) { set_error("out of host memory"); return QGX_ERR_NOMEM; }
+    m->cfg = *cfg;
+    m->N = N; m->NK = N / 2 + 1; m->B = cfg->n_members;
+    const int NK = m->NK, B = m->B;
+    const double pi = 3.14159265358979323846;
+    const double L = cfg->L, W = cfg->L;
+
+    // pyqg model.py::_initialize_grid
+    const double dk = 2. * pi / L, dl = 2. * pi / W;
+    m->h_kk.resize(NK); m->h_ll.resize(N);
+    for (int i = 0; i < NK; ++i) m->h_kk[i] = dk * (double)i;
+    for (int j = 0; j < N; ++j) m->h_ll[j] = dl * (double)(j < N / 2 ? j : j - N);
+    const double dx = L / N, dy = W / N;
+    m->h_wv2.resize((size_t)N * NK); m->h_filtr.resize((size_t)N * NK); m->h_a.resize((size_t)4 * N * NK);
+    // pyqg qg_model.py::_initialize_background
+    const double F1 = pow(cfg->rd, -2.0) / (1. + cfg->delta);
+    const double F2 = cfg->delta * F1;
+    const double Qy1 = cfg->beta + F1 * (cfg->U1 - cfg->U2);
+    const double Qy2 = cfg->beta - F2 * (cfg->U1 - cfg->U2);
+    const double cphi = 0.65 * pi;
+    const size_t sz = (size_t)N * NK;
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < NK; ++i) {
+            const double k = m->h_kk[i], l = m->h_ll[j];
+            const double wv2 = k * k + l * l;
+            const size_t o = (size_t)j * NK + i;
+            m->h_wv2[o] = wv2;
+            // model.py::_initialize_filter
+            const double wvx = sqrt((k * dx) * (k * dx) + (l * dy) * (l * dy));
+            m->h_filtr[o] = wvx <= cphi ? 1.0 : exp(-cfg->filterfac * pow(wvx - cphi, 4.));
+            // qg_model.py::_initialize_inversion_matrix
+            const double det = wv2 * (wv2 + F1 + F2);
+            const double det_inv = det != 0. ? 1.0 / det : 0.;
+            m->h_a[0 * sz + o] = -(wv2 + F2) * det_inv;
+            m->h_a[1 * sz + o] = -F1 * det_inv;
+            m->h_a[2 * sz + o] = -F2 * det_inv;
+            m->h_a[3 * sz + o] = -(wv2 + F1) * det_inv;
+            if (det == 0.) for (int t = 0; t < 4; ++t) m->h_a[t * sz + o] = 0.;
+        }
+    // twiddles and the digit-reversal map of the DIF passes
+    std::vector<double2> tw(N);
+    for (int t = 0; t < N; ++t) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)t / (long double)N;
+        tw[t] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    std::vector<int> pos(N);
+    for (int P = 0; P < N; ++P) {
+        int rem = P, kf = 0, mult = 1, n = N;
+        for (int p = 0; p < nrad; ++p) {
+            n /= rad[p];
+            const int qd = rem / n;
+            rem -= qd * n;
+            kf += qd * mult;
+            mult *= rad[p];
+        }
+        pos[kf] = P;
+    }
+    int rc;
+    if ((rc = upload(m->t_filtr, m->h_filtr)) || (rc = upload(m->t_wv2, m->h_wv2)) ||
+        (rc = upload(m->t_a, m->h_a)) || (rc = upload(m->t_kk, m->h_kk)) ||
+        (rc = upload(m->t_ll, m->h_ll)) || (rc = upload(m->t_tw, tw)) || (rc = upload(m->t_pos, pos))) {
+        qgx_destroy(m);
+        return rc;
+    }
+    SpecDev &d = m->d;
+    d.N = N; d.NK = NK; d.LD = N + 1; d.B = B; d.nrad = nrad;
+    for (int p = 0; p < MAX_RADIX_PASSES; ++p) d.rad[p] = p < nrad ? rad[p] : 1;
+    d.filtr = m->t_filtr; d.wv2 = m->t_wv2; d.a = m->t_a; d.kk = m->t_kk; d.ll = m->t_ll;
+    d.tw = m->t_tw; d.pos = m->t_pos;
+    d.U[0] = cfg->U1; d.U[1] = cfg->U2; d.Qy[0] = Qy1; d.Qy[1] = Qy2;
+    d.rek = cfg->rek; d.invN2 = 1.0 / ((double)N * (double)N); d.dt = cfg->dt; d.dx = dx;
+    d.H[0] = cfg->H1; d.H[1] = cfg->H1 / cfg->delta; d.Htot = d.H[0] + d.H[1];
+
+    const size_t nr = (size_t)B * 2 * N * N, ns = (size_t)B * 2 * N * NK;
+    if ((rc = dalloc(m->q, nr)) || (rc = dalloc(m->u, nr)) || (rc = dalloc(m->v, nr)) ||
+        (rc = dalloc(m->S, nr)) || (rc = dalloc(m->qh[0], ns)) || (rc = dalloc(m->qh[1], ns)) ||
+        (rc = dalloc(m->ph, ns)) || (rc = dalloc(m->dqh, ns)) || (rc = dalloc(m->dq[0], ns)) ||
+        (rc = dalloc(m->dq[1], ns)) || (rc = dalloc(m->dq[2], ns))) {
+        qgx_destroy(m);
+        return rc;
+    }
+    {   // latent noise + scratch sized for the wider (double) case
+        void *p = nullptr, *p2 = nullptr;
+        if (hipMalloc(&p, nr * sizeof(double)) != hipSuccess || hipMalloc(&p2, nr * sizeof(double)) != hipSuccess) {
+            set_error("hipMalloc of noise buffers failed");
+            qgx_destroy(m);
+            return QGX_ERR_HIP;
+        }
+        hipMemset(p, 0, nr * sizeof(double));
+        hipMemset(p2, 0, nr * sizeof(double));
+        m->z = p; m->xi = p2;
+    }
+    m->small = small_path_fits(N);
+    if (m->small) rc = small_prepare(d);
+    else {
+        rc = dalloc(m->zbuf, (size_t)B * 2 * N * N);
+        if (!rc) rc = large_prepare(d);
+    }
+    if (rc) { qgx_destroy(m); return rc; }
+    *out = m;
+    return QGX_OK;
+}
+
+extern "C" int qgx_destroy(qgx_model *m) {
+    if (!m) return QGX_OK;
+    hipSetDevice(m->cfg.device);
+    void *ptrs[] = {m->t_filtr, m->t_wv2, m->t_a, m->t_kk, m->t_ll, m->t_tw, m->t_pos, m->q, m->u, m->v,
+                    m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->zbuf,
+                    m->z, m->xi};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete m;
+    return QGX_OK;
+}
+
+extern "C" size_t qgx_field_bytes(const qgx_model *m, int field) {
+    if (!m) return 0;
+    const size_t nr = (size_t)m->B * 2 * m->N * m->N, ns = (size_t)m->B * 2 * m->N * m->NK;
+    switch (field) {
+        case QGX_F_Q: case QGX_F_U: case QGX_F_V: case QGX_F_S: return nr * sizeof(double);
+        case QGX_F_QH: case QGX_F_PH: case QGX_F_DQHDT: case QGX_F_DQHDT_P: case QGX_F_DQHDT_PP:
+            return ns * sizeof(double2);
+        case QGX_F_Z: return nr * (m->z_double ? sizeof(double) : sizeof(float));
+        default: return 0;
+    }
+}
+
+extern "C" int qgx_get(qgx_model *m, int field, void *out_dev, void *stream) {
+    QGX_REQUIRE(m && out_dev, "qgx_get: null argument");
+    const void *src = nullptr;
+    switch (field) {
+        case QGX_F_Q: src = m->q; break;
+        case QGX_F_U: src = m->u; break;
+        case QGX_F_V: src = m->v; break;
+        case QGX_F_S: src = m->S; break;
+        case QGX_F_QH: src = m->qh[m->cur_q]; break;
+        case QGX_F_PH: src = m->ph; break;
+        case QGX_F_DQHDT: src = m->dq[m->i_new]; break;
+        // kernel.pyx rotates by copy: after a step dqhdt_p == dqhdt and dqhdt_pp is the previous one
+        case QGX_F_DQHDT_P: src = m->dq[m->i_new]; break;
+        case QGX_F_DQHDT_PP: src = m->dq[m->i_p]; break;
+        case QGX_F_Z: src = m->z; break;
+        default: QGX_REQUIRE(false, "qgx_get: unknown field %d", field);
+    }
+    QGX_HIP(hipMemcpyAsync(out_dev, src, qgx_field_bytes(m, field), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return QGX_OK;
+}
+
+extern "C" int qgx_get_table(qgx_model *m, int table, double *out) {
+    QGX_REQUIRE(m && out, "qgx_get_table: null argument");
+    const std::vector<double> *v = nullptr;
+    switch (table) {
+        case QGX_T_FILTR: v = &m->h_filtr; break;
+        case QGX_T_WV2: v = &m->h_wv2; break;
+        case QGX_T_A: v = &m->h_a; break;
+        case QGX_T_KK: v = &m->h_kk; break;
+        case QGX_T_LL: v = &m->h_ll; break;
+        default: QGX_REQUIRE(false, "qgx_get_table: unknown table %d", table);
+    }
+    memcpy(out, v->data(), v->size() * sizeof(double));
+    return QGX_OK;
+}
+
+extern "C" int qgx_set_q(qgx_model *m, const double *q_dev, void *stream) {
+    QGX_REQUIRE(m && q_dev, "qgx_set_q: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    QGX_HIP(hipMemcpyAsync(m->q, q_dev, qgx_field_bytes(m, QGX_F_Q), hipMemcpyDeviceToDevice, st));
+    return m->small ? small_q_to_qh(m->d, m->q, m->qh[m->cur_q], st) : large_q_to_qh(m, m->q, m->qh[m->cur_q], st);
+}
+
+extern "C" int qgx_set_qh(qgx_model *m, const double *qh_dev, void *stream) {
+    QGX_REQUIRE(m && qh_dev, "qgx_set_qh: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    QGX_HIP(hipMemcpyAsync(m->qh[m->cur_q], qh_dev, qgx_field_bytes(m, QGX_F_QH), hipMemcpyDeviceToDevice, st));
+    return m->small ? small_qh_to_q(m->d, m->qh[m->cur_q], m->q, st) : large_qh_to_q(m, m->qh[m->cur_q], m->q, st);
+}
+
+extern "C" int qgx_invert(qgx_model *m, void *stream) {
+    QGX_REQUIRE(m, "qgx_invert: null model");
+    hipStream_t st = (hipStream_t)stream;
+    return m->small ? small_invert(m->d, m->qh[m->cur_q], m->ph, m->u, m->v, st) : large_invert(m, st);
+}
+
+extern "C" int64_t qgx_step_count(const qgx_model *m) { return m ? m->tc : -1; }
+
+extern "C" int qgx_reset_time(qgx_model *m) {
+    QGX_REQUIRE(m, "qgx_reset_time: null model");
+    m->tc = 0; m->ablevel = 0; m->have_noise = false; m->const_counter = 0; m->have_forcing = false;
+    const size_t ns = (size_t)m->B * 2 * m->N * m->NK;
+    for (int i = 0; i < 3; ++i) QGX_HIP(hipMemset(m->dq[i], 0, ns * sizeof(double2)));
+    return QGX_OK;
+}
+
+extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
+    QGX_REQUIRE(m && out_dev, "qgx_status_ke_cfl: null argument");
+    hipLaunchKernelGGL(k_status, dim3(m->B), dim3(256), 0, (hipStream_t)stream, m->d, m->ph, m->u, m->v, out_dev);
+    QGX_HIP(hipGetLastError());
+    return QGX_OK;
+}
+
+// ---- the stepping loop: pyqg model.py::_step_forward with the plugin call of
+// pyqg_generative/models/parameterization.py:23-34 and samplers of stochastic_pyqg.py:30-72
+extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refresh_diag, void *stream) {
+    QGX_REQUIRE(m && nsteps >= 0, "qgx_step: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = m->N, B = m->B;
+    if (p && p->gen) {
+        QGX_REQUIRE(p->sampling == QGX_SAMPLING_AR1 || p->sampling == QGX_SAMPLING_CONSTANT,
+                    "qgx_step: unknown sampling %d", p->sampling);
+        QGX_REQUIRE(!(p->sampling == QGX_SAMPLING_CONSTANT && p->nsteps < 1),
+                    "qgx_step: constant sampler needs nsteps >= 1");
+        QGX_REQUIRE(p->nsteps != 0, "qgx_step: nsteps == 0 is not a valid decorrelation time");
+        QGX_REQUIRE(!(p->z_external_dev && nsteps != 1), "qgx_step: external noise needs nsteps_to_run == 1");
+        m->z_double = generator_noise_is_double(p->gen);
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        bool has_S = false;
+        const double *S = nullptr;
+        double weight = 1.0;
+        int demean_in_kernel = 0;
+        if (p && p->gen) {
+            weight = p->weight;
+            bool compute = true;
+            double a = 0.0, b = 1.0;
+            bool draw = true;
+            if (p->sampling == QGX_SAMPLING_AR1) {
+                if (m->have_noise) {
+                    if (p->nsteps > 0) {
+                        a = 1.0 - 1.0 / p->nsteps;
+                        b = sqrt(1.0 / p->nsteps * (2.0 - 1.0 / p->nsteps));
+                    } else { a = 1.0; b = 0.0; }
+                }
+            } else {
+                if (m->have_noise) {
+                    if (m->const_counter % p->nsteps == 0) m->const_counter = 1;
+                    else { m->const_counter += 1; compute = false; draw = false; }
+                } else m->const_counter = 1;
+            }
+            if (draw) {
+                const int npm = 2 * N * N;
+                int rc = noise_update(m->z, p->z_external_dev, m->z_double, B, npm, p->seed,
+                                      p->member_offset, m->noise_step, a, b, st);
+                if (rc) return rc;
+                m->noise_step += 1;
+                m->have_noise = true;
+            }
+            if (compute) {
+                int rc = generator_forward(p->gen, m->q, m->z, m->S, B, N, p->demean, st);
+                if (rc) return rc;
+                m->have_forcing = true;
+            }
+            has_S = m->have_forcing;
+            S = m->S;
+        } else if (p && p->forcing_dev) {
+            has_S = true;
+            S = p->forcing_dev;
+            weight = p->weight;
+            demean_in_kernel = p->demean;
+        }
+        const int diag = (refresh_diag && s == nsteps - 1) ? 1 : 0;
+        int rc = model_step_once(m, has_S, S, weight, demean_in_kernel, diag, st);
+        if (rc) return rc;
+    }
+    return QGX_OK;
+}

@@ -1,0 +1,207 @@
+"""Thin object wrappers over the C ABI (include/qgx.h).
+
+PyTorch tensors are used as device-memory containers and for the stream only;
+all arithmetic happens inside libqgx.so.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+PYQG_DEFAULTS = dict(L=1e6, dt=7200., rek=5.787e-7, delta=0.25, beta=1.5e-11, rd=15000.0,
+                     U1=0.025, U2=0.0, H1=500., filterfac=23.6)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Generator:
+    """Device-resident generator (CGAN G / CVAE decoder / GZ mean+var nets)."""
+    KINDS = {'gan': _lib.GEN_GAN, 'vae': _lib.GEN_VAE, 'gz': _lib.GEN_GZ}
+
+    def __init__(self, kind, nets, x_std, y_std, device=0):
+        """nets: list of dicts with float32 numpy arrays
+        conv_w[8], conv_b[8], bn_g[7], bn_b[7], bn_m[7], bn_v[7] (PyTorch layouts)."""
+        self.kind = kind
+        self.device = device
+        self._h = C.c_void_p(0)
+        keep = []
+        arr = (_lib.qgx_cnn_weights * len(nets))()
+        for n, net in enumerate(nets):
+            w = arr[n]
+            w.n_in = int(net['conv_w'][0].shape[1])
+            w.n_out = int(net['conv_w'][7].shape[0])
+            w.bn_eps = 1e-5
+            for i in range(8):
+                cw = np.ascontiguousarray(net['conv_w'][i], dtype=np.float32)
+                cb = np.ascontiguousarray(net['conv_b'][i], dtype=np.float32)
+                keep += [cw, cb]
+                w.conv_w[i] = cw.ctypes.data
+                w.conv_b[i] = cb.ctypes.data
+            for i in range(7):
+                for field, key in (('bn_gamma', 'bn_g'), ('bn_beta', 'bn_b'),
+                                   ('bn_mean', 'bn_m'), ('bn_var', 'bn_v')):
+                    a = np.ascontiguousarray(net[key][i], dtype=np.float32)
+                    keep.append(a)
+                    getattr(w, field)[i] = a.ctypes.data
+        xs = (C.c_float * 2)(*[float(v) for v in np.asarray(x_std, np.float32).reshape(-1)])
+        ys = (C.c_float * 2)(*[float(v) for v in np.asarray(y_std, np.float32).reshape(-1)])
+        self.x_std = np.asarray(x_std, np.float32).reshape(-1)
+        self.y_std = np.asarray(y_std, np.float32).reshape(-1)
+        check(lib.qgx_generator_create(self.KINDS[kind], arr, len(nets), xs, ys, device, C.byref(self._h)))
+        self.n_in = 2 if kind == 'gz' else 4
+
+    @property
+    def noise_dtype(self):
+        return torch.float64 if self.kind == 'gz' else torch.float32
+
+    def forward(self, q, z, demean=True, out=None):
+        """q: (B,2,N,N) float64 cuda; z: (B,2,N,N) float32 (float64 for gz) -> S (B,2,N,N) float64."""
+        assert q.is_cuda and q.dtype == torch.float64 and q.is_contiguous() and q.dim() == 4
+        assert z.is_cuda and z.dtype == self.noise_dtype and z.is_contiguous()
+        B, _, N, _ = q.shape
+        assert z.numel() == q.numel()
+        S = out if out is not None else torch.empty_like(q)
+        check(lib.qgx_generator_forward(self._h, _ptr(q), _ptr(z), _ptr(S), B, N, int(bool(demean)), _stream()))
+        return S
+
+    def cnn_forward(self, x, inet=0):
+        """Raw AndrewCNN forward: x (B,n_in,N,N) float32 -> (B,2,N,N) float32."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == self.n_in
+        B, _, N, _ = x.shape
+        y = torch.empty((B, 2, N, N), dtype=torch.float32, device=x.device)
+        check(lib.qgx_cnn_forward(self._h, inet, _ptr(x), _ptr(y), B, N, _stream()))
+        return y
+
+    def close(self):
+        if self._h:
+            lib.qgx_generator_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EnsembleEngine:
+    """B independent two-layer QG members resident on one GPU."""
+
+    def __init__(self, nx=64, n_members=1, device=0, **params):
+        cfg = _lib.qgx_config()
+        p = dict(PYQG_DEFAULTS)
+        for k, v in params.items():
+            if k not in p:
+                raise TypeError(f'unknown model parameter {k!r}')
+            p[k] = v
+        cfg.nx, cfg.n_members, cfg.device = int(nx), int(n_members), int(device)
+        for k, v in p.items():
+            setattr(cfg, k, float(v))
+        self.params = p
+        self.N, self.NK, self.B = int(nx), int(nx) // 2 + 1, int(n_members)
+        self.device = torch.device('cuda', device)
+        self._h = C.c_void_p(0)
+        check(lib.qgx_create(C.byref(cfg), C.byref(self._h)))
+
+    # ---- tables -------------------------------------------------------------------
+    def table(self, which):
+        N, NK = self.N, self.NK
+        shape = {_lib.T_FILTR: (N, NK), _lib.T_WV2: (N, NK), _lib.T_A: (2, 2, N, NK),
+                 _lib.T_KK: (NK,), _lib.T_LL: (N,)}[which]
+        out = np.empty(shape, dtype=np.float64)
+        check(lib.qgx_get_table(self._h, which, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ---- state --------------------------------------------------------------------
+    def _real(self):
+        return torch.empty((self.B, 2, self.N, self.N), dtype=torch.float64, device=self.device)
+
+    def _spec(self):
+        return torch.empty((self.B, 2, self.N, self.NK), dtype=torch.complex128, device=self.device)
+
+    def get(self, field, noise_dtype=torch.float32):
+        if field in (_lib.F_Q, _lib.F_U, _lib.F_V, _lib.F_S):
+            out = self._real()
+        elif field == _lib.F_Z:
+            out = torch.empty((self.B, 2, self.N, self.N), dtype=noise_dtype, device=self.device)
+        else:
+            out = self._spec()
+        check(lib.qgx_get(self._h, field, _ptr(out), _stream()))
+        return out
+
+    def set_q(self, q):
+        q = torch.as_tensor(q, dtype=torch.float64, device=self.device).contiguous()
+        assert tuple(q.shape) == (self.B, 2, self.N, self.N), q.shape
+        check(lib.qgx_set_q(self._h, _ptr(q), _stream()))
+        torch.cuda.current_stream().synchronize()     # q may be a temporary
+
+    def set_qh(self, qh):
+        qh = torch.as_tensor(qh, dtype=torch.complex128, device=self.device).contiguous()
+        assert tuple(qh.shape) == (self.B, 2, self.N, self.NK), qh.shape
+        check(lib.qgx_set_qh(self._h, _ptr(qh), _stream()))
+        torch.cuda.current_stream().synchronize()
+
+    def invert(self):
+        check(lib.qgx_invert(self._h, _stream()))
+
+    @property
+    def tc(self):
+        return int(lib.qgx_step_count(self._h))
+
+    def reset_time(self):
+        check(lib.qgx_reset_time(self._h))
+
+    def status(self):
+        """-> (KE[B], CFL[B]) as pyqg's _print_status computes them (from the last inversion)."""
+        out = torch.empty((self.B, 2), dtype=torch.float64, device=self.device)
+        check(lib.qgx_status_ke_cfl(self._h, _ptr(out), _stream()))
+        out = out.cpu().numpy()
+        return out[:, 0], out[:, 1]
+
+    # ---- stepping -----------------------------------------------------------------
+    def step(self, nsteps=1, generator=None, sampling='AR1', nsteps_decor=1, weight=1.0, seed=0,
+             member_offset=0, z_external=None, forcing=None, demean=None, refresh_diag=True):
+        p = None
+        keep = []
+        if generator is not None or forcing is not None:
+            p = _lib.qgx_param()
+            p.gen = generator._h if generator is not None else None
+            p.sampling = {'AR1': _lib.SAMPLING_AR1, 'constant': _lib.SAMPLING_CONSTANT}[sampling]
+            p.nsteps = int(nsteps_decor)
+            p.weight = float(weight)
+            p.seed = int(seed)
+            p.member_offset = int(member_offset)
+            if z_external is not None:
+                assert z_external.is_cuda and z_external.is_contiguous()
+                keep.append(z_external)
+                p.z_external_dev = z_external.data_ptr()
+            if forcing is not None:
+                assert forcing.is_cuda and forcing.dtype == torch.float64 and forcing.is_contiguous()
+                keep.append(forcing)
+                p.forcing_dev = forcing.data_ptr()
+            if demean is None:
+                demean = generator is not None
+            p.demean = int(bool(demean))
+        check(lib.qgx_step(self._h, int(nsteps), C.byref(p) if p is not None else None,
+                           int(bool(refresh_diag)), _stream()))
+        if keep:
+            torch.cuda.current_stream().synchronize()
+
+    def close(self):
+        if self._h:
+            lib.qgx_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,47 @@
+"""CPU: the C-ABI library loads and exports every symbol include/qgx.h declares
+(no compute calls without a GPU)."""
+import os
+import re
+import ctypes
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'qgx.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(qgx_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pyqg_generative_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 19
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert set(declared) == bound, (set(declared) ^ bound)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert getattr(raw, name) is not None
+
+
+def test_version_and_error_string_without_gpu():
+    from pyqg_generative_amd import _lib
+    assert b'gfx950' in _lib.lib.qgx_version()
+    assert isinstance(_lib.lib.qgx_last_error(), bytes)
+
+
+def test_struct_sizes_match_header():
+    from pyqg_generative_amd import _lib
+    assert ctypes.sizeof(_lib.qgx_config) == 16 + 10 * 8
+    assert ctypes.sizeof(_lib.qgx_param) == 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert ctypes.sizeof(_lib.qgx_cnn_weights) == 8 + 8 * (8 + 8 + 7 * 4) + 8
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from pyqg_generative_amd import _lib
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    try:
+        _lib._load()
+    except ImportError as e:
+        assert 'no CPU fallback' in str(e)
+    else:
+        raise AssertionError('loading a missing library must raise')

@@ -1,0 +1,269 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerances (stated per test):
+  * spectral core, float64: relative 1e-12 of the field maximum (FFT butterflies are
+    ordered differently from pocketfft, so bit equality is not expected)
+  * generator, float32 arithmetic: 2e-5 of the field maximum against the golden
+    vectors captured from the reference (different summation order than MIOpen/oneDNN)
+"""
+import os
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from conftest import golden, load_generator, GOLDEN
+from oracle import qg_ref, gen_ref, samplers_ref
+
+F64_TOL = 1e-12
+
+
+def _engine(N, B, **kw):
+    import pyqg_generative_amd as qa
+    return qa.EnsembleEngine(nx=N, n_members=B, **kw)
+
+
+def _gpu_generator(kind):
+    import pyqg_generative_amd as qa
+    from pyqg_generative_amd import weights
+    nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind)
+    return qa.Generator(kind, nets, xs, ys)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _random_q(rs, B, N):
+    return rs.randn(B, 2, N, N) * np.array([8e-6, 1e-6])[None, :, None, None]
+
+
+def _eddy_like_q(rs, B, N):
+    """smooth fields with eddy-like amplitudes (white noise band-limited to 2/3 Nyquist)"""
+    m = qg_ref.QGModelRef(nx=N)
+    q = _random_q(rs, B, N)
+    qh = np.fft.rfftn(q, axes=(-2, -1)) * (m.wv < 2. / 3. * m.kk[-1])
+    return np.fft.irfftn(qh, axes=(-2, -1)) * 3.0
+
+
+@pytest.mark.parametrize('N', [32, 48, 64, 96])
+def test_q_qh_roundtrip_and_invert(N):
+    import pyqg_generative_amd._lib as L
+    B = 3
+    rs = np.random.RandomState(N)
+    q = _random_q(rs, B, N)            # white noise: exercises the Nyquist rows/columns too
+    e = _engine(N, B)
+    e.set_q(q)
+    qh = e.get(L.F_QH).cpu().numpy()
+    ref = np.fft.rfftn(q, axes=(-2, -1))
+    assert _rel(qh, ref) < F64_TOL
+    e.invert()
+    ph, u, v = (e.get(f).cpu().numpy() for f in (L.F_PH, L.F_U, L.F_V))
+    for b in range(B):
+        m = qg_ref.QGModelRef(nx=N)
+        m.set_q(q[b])
+        m._invert()
+        assert _rel(ph[b], m.ph) < F64_TOL
+        assert _rel(u[b], m.u) < F64_TOL and _rel(v[b], m.v) < F64_TOL
+    # qh setter refreshes q
+    e.set_qh(ref)
+    assert _rel(e.get(L.F_Q).cpu().numpy(), q) < F64_TOL
+    # grid tables, bit for bit against the oracle's numpy expressions
+    m = qg_ref.QGModelRef(nx=N)
+    np.testing.assert_array_equal(e.table(L.T_KK), m.kk)
+    np.testing.assert_array_equal(e.table(L.T_LL), m.ll)
+    np.testing.assert_array_equal(e.table(L.T_WV2), m.wv2)
+    np.testing.assert_array_equal(e.table(L.T_A), m.a)
+    np.testing.assert_allclose(e.table(L.T_FILTR), m.filtr, rtol=4e-16, atol=0)
+
+
+@pytest.mark.parametrize('N,params', [(64, dict(dt=14400.)), (48, dict(dt=14400.)),
+                                      (96, dict(dt=7200., rek=7e-8, delta=0.1, beta=1e-11)),
+                                      (32, dict(dt=14400.))])
+def test_unparameterized_steps_match_oracle(N, params):
+    """configs[0] physics on the GPU: Euler -> AB2 -> AB3 start-up, filter, friction."""
+    import pyqg_generative_amd._lib as L
+    B, nsteps = 3, 12
+    rs = np.random.RandomState(100 + N)
+    q0 = _eddy_like_q(rs, B, N)
+    e = _engine(N, B, **params)
+    e.set_q(q0)
+    refs = []
+    for b in range(B):
+        m = qg_ref.QGModelRef(nx=N, **params)
+        m.set_q(q0[b])
+        refs.append(m)
+    for s in range(nsteps):
+        e.step(1)
+        for m in refs:
+            m._step_forward()
+        qh = e.get(L.F_QH).cpu().numpy()
+        q = e.get(L.F_Q).cpu().numpy()
+        for b, m in enumerate(refs):
+            assert _rel(qh[b], m.qh) < F64_TOL * (s + 1), (s, b)
+            assert _rel(q[b], m.q) < F64_TOL * (s + 1), (s, b)
+    # fields pyqg keeps from the last inversion + tendencies
+    ph, u, v = (e.get(f).cpu().numpy() for f in (L.F_PH, L.F_U, L.F_V))
+    dq = e.get(L.F_DQHDT).cpu().numpy()
+    dqpp = e.get(L.F_DQHDT_PP).cpu().numpy()
+    for b, m in enumerate(refs):
+        assert _rel(ph[b], m.ph) < 1e-11 and _rel(u[b], m.u) < 1e-11 and _rel(v[b], m.v) < 1e-11
+        assert _rel(dq[b], m.dqhdt_p) < 1e-10 and _rel(dqpp[b], m.dqhdt_pp) < 1e-10
+    ke, cfl = e.status()
+    for b, m in enumerate(refs):
+        assert abs(ke[b] - m._calc_ke()) < 1e-11 * m._calc_ke()
+        assert abs(cfl[b] - m._calc_cfl()) < 1e-11
+    assert e.tc == nsteps
+
+
+def test_many_steps_in_one_call_equals_single_steps():
+    import pyqg_generative_amd._lib as L
+    N, B = 64, 2
+    q0 = _eddy_like_q(np.random.RandomState(5), B, N)
+    e1, e2 = _engine(N, B, dt=14400.), _engine(N, B, dt=14400.)
+    e1.set_q(q0)
+    e2.set_q(q0)
+    e1.step(25)
+    for _ in range(25):
+        e2.step(1)
+    assert torch.equal(e1.get(L.F_QH), e2.get(L.F_QH))       # deterministic: bit-identical
+
+
+def test_external_forcing_matches_oracle_q_parameterization():
+    import pyqg_generative_amd._lib as L
+    N, B = 64, 2
+    rs = np.random.RandomState(9)
+    q0 = _eddy_like_q(rs, B, N)
+    Ss = [rs.randn(B, 2, N, N) * np.array([7e-12, 2e-13])[None, :, None, None] for _ in range(4)]
+    e = _engine(N, B, dt=14400.)
+    e.set_q(q0)
+    refs = []
+    for b in range(B):
+        it = iter([s[b] for s in Ss])
+        m = qg_ref.QGModelRef(nx=N, dt=14400., parameterization=(lambda it: lambda mm: 0.5 * next(it))(it))
+        m.set_q(q0[b])
+        refs.append(m)
+    for s in range(4):
+        e.step(1, forcing=torch.as_tensor(Ss[s]).cuda(), weight=0.5, demean=False)
+        for m in refs:
+            m._step_forward()
+    qh = e.get(L.F_QH).cpu().numpy()
+    for b, m in enumerate(refs):
+        assert _rel(qh[b], m.qh) < 1e-11
+
+
+@pytest.mark.parametrize('kind', ['gan', 'vae', 'gz'])
+@pytest.mark.parametrize('N', [48, 64, 96])
+def test_generator_matches_reference_golden(kind, N):
+    g = golden('generator.npz')
+    gen = _gpu_generator(kind)
+    q = torch.as_tensor(g[f'{kind}_{N}_q'].astype('float64')[None]).cuda().contiguous()
+    z = g[f'{kind}_{N}_z']
+    z = torch.as_tensor(z.reshape(1, 2, N, N)).cuda().contiguous()
+    S = gen.forward(q, z, demean=True).cpu().numpy()[0]
+    Sraw = gen.forward(q, z, demean=False).cpu().numpy()[0]
+    ref, ref_raw = g[f'{kind}_{N}_S'], g[f'{kind}_{N}_Sraw']
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(Sraw - ref_raw) / scale).max() < 2e-5
+    assert (np.abs(S - ref) / scale).max() < 2e-5
+    assert np.abs(S.mean(axis=(1, 2))).max() < 1e-14 * scale.max() * N * N
+
+
+def test_cnn_layers_match_reference_batched():
+    """Batched raw CNN forward (B=5, N=32) against the oracle's torch-CPU restatement."""
+    gen = _gpu_generator('gan')
+    ora = load_generator('gan')
+    rs = np.random.RandomState(2)
+    x = rs.randn(5, 4, 32, 32).astype('float32')
+    y = gen.cnn_forward(torch.as_tensor(x).cuda()).cpu().numpy()
+    ref = gen_ref.cnn_forward(ora.nets[0], x)
+    assert np.abs(y - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+def test_philox_noise_matches_oracle_stream():
+    import ctypes as C
+    from pyqg_generative_amd._lib import lib, check
+    B, n = 3, 2 * 16 * 16
+    z = torch.zeros((B, n), dtype=torch.float32, device='cuda')
+    check(lib.qgx_noise_normal(C.c_void_p(z.data_ptr()), 0, B, n, 0x1234567890ABCDEF, 10, 7, 0.0, 1.0, None))
+    torch.cuda.synchronize()
+    z = z.cpu().numpy()
+    for b in range(B):
+        ref, _ = samplers_ref.philox_normal(0x1234567890ABCDEF, 10 + b, 7, n)
+        assert np.abs(z[b] - ref).max() < 2e-5       # device logf/sincosf vs numpy: few ulp
+    # AR1 update z <- a z + b xi in float32, double flavour, distribution
+    zd = torch.zeros((1, 1 << 18), dtype=torch.float64, device='cuda')
+    check(lib.qgx_noise_normal(C.c_void_p(zd.data_ptr()), 1, 1, 1 << 18, 1, 0, 0, 0.0, 1.0, None))
+    torch.cuda.synchronize()
+    s = zd.cpu().numpy().ravel()
+    assert abs(s.mean()) < 0.01 and abs(s.std() - 1) < 0.01 and abs((s ** 4).mean() - 3) < 0.1
+
+
+@pytest.mark.parametrize('kind,sampling,nd', [('gan', 'AR1', 1), ('vae', 'AR1', 3), ('gz', 'constant', 2),
+                                              ('gan', 'constant', 1)])
+def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd):
+    """configs[1] (B=1..2): full online step = sampler + generator + de-mean + spectral step,
+    with the white noise xi supplied externally so that both sides see identical draws."""
+    import pyqg_generative_amd._lib as L
+    N, B, nsteps = 64, 2, 5
+    rs = np.random.RandomState(77)
+    q0 = _eddy_like_q(rs, B, N)
+    gen = _gpu_generator(kind)
+    ora = load_generator(kind)
+    e = _engine(N, B, dt=14400.)
+    e.set_q(q0)
+    if kind == 'gz':
+        xis = [rs.randn(B, 2, N, N) for _ in range(nsteps)]
+    else:
+        xis = [rs.randn(B, 1, 2, N, N).astype('float32') for _ in range(nsteps)]
+    refs = []
+    for b in range(B):
+        it = iter([x[b] for x in xis])
+
+        class _Rng:          # feeds the external draws to generate_latent_noise
+            def __init__(self, it):
+                self.it = it
+
+            def randn(self, *shape):
+                return next(self.it).astype('float64').reshape(shape)
+        m = qg_ref.QGModelRef(nx=N, dt=14400.)
+        m.sampling_type = sampling
+        m.noise_sampler = samplers_ref.make_sampler(sampling, nd)
+        m.q_parameterization = gen_ref.ParameterizationRef(ora, rng=_Rng(it))
+        m.set_q(q0[b])
+        refs.append(m)
+    for s in range(nsteps):
+        xi = torch.as_tensor(np.ascontiguousarray(xis[s].reshape(B, 2, N, N))).cuda()
+        e.step(1, generator=gen, sampling=sampling, nsteps_decor=nd, z_external=xi)
+        for m in refs:
+            m._step_forward()
+        qh = e.get(L.F_QH).cpu().numpy()
+        S = e.get(L.F_S).cpu().numpy()
+        for b, m in enumerate(refs):
+            sc = np.abs(m.PV_forcing).max(axis=(1, 2), keepdims=True)
+            assert (np.abs(S[b] - m.PV_forcing) / sc).max() < 5e-5, (s, b)
+            # the f32 generator difference enters qh scaled by dt*|S|/|q| ~ 1e-2 per step
+            assert _rel(qh[b], m.qh) < 2e-6, (s, b)
+
+
+def test_on_device_noise_run_is_reproducible_and_member_streams_differ():
+    import pyqg_generative_amd._lib as L
+    N, B = 64, 4
+    q0 = _eddy_like_q(np.random.RandomState(1), 1, N).repeat(B, axis=0)
+    gen = _gpu_generator('gan')
+    outs = []
+    for trial in range(2):
+        e = _engine(N, B, dt=14400.)
+        e.set_q(q0)
+        e.step(6, generator=gen, sampling='AR1', nsteps_decor=1, seed=42)
+        outs.append(e.get(L.F_Q))
+    assert torch.equal(outs[0], outs[1])
+    q = outs[0].cpu().numpy()
+    assert np.isfinite(q).all()
+    assert np.abs(q[0] - q[1]).max() > 0          # identical IC, different noise stream per member
+    # sharding: members 2..3 of a 4-member run == a 2-member run with member_offset=2
+    e = _engine(N, 2, dt=14400.)
+    e.set_q(q0[:2])
+    e.step(6, generator=gen, sampling='AR1', nsteps_decor=1, seed=42, member_offset=2)
+    assert torch.equal(e.get(L.F_Q), outs[0][2:])
