@@ -75,7 +75,8 @@ def test_q_qh_roundtrip_and_invert(N):
     np.testing.assert_array_equal(e.table(L.T_LL), m.ll)
     np.testing.assert_array_equal(e.table(L.T_WV2), m.wv2)
     np.testing.assert_array_equal(e.table(L.T_A), m.a)
-    np.testing.assert_allclose(e.table(L.T_FILTR), m.filtr, rtol=4e-16, atol=0)
+    # exp(-23.6 x^4) with x^4 from libm pow vs numpy power: ulp differences amplified by the exponent
+    np.testing.assert_allclose(e.table(L.T_FILTR), m.filtr, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize('N,params', [(64, dict(dt=14400.)), (48, dict(dt=14400.)),
@@ -233,8 +234,13 @@ def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd
         m.q_parameterization = gen_ref.ParameterizationRef(ora, rng=_Rng(it))
         m.set_q(q0[b])
         refs.append(m)
+    draws = 0
     for s in range(nsteps):
-        xi = torch.as_tensor(np.ascontiguousarray(xis[s].reshape(B, 2, N, N))).cuda()
+        # the oracle consumes one external draw per sampler refresh: every step for AR1,
+        # every nd-th step for the constant sampler (stochastic_pyqg.py:62-71)
+        xi = torch.as_tensor(np.ascontiguousarray(xis[draws].reshape(B, 2, N, N))).cuda()
+        if sampling == 'AR1' or s % nd == 0:
+            draws += 1
         e.step(1, generator=gen, sampling=sampling, nsteps_decor=nd, z_external=xi)
         for m in refs:
             m._step_forward()
