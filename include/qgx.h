@@ -159,6 +159,13 @@ int qgx_generator_forward(qgx_generator *g, const double *q_dev, const void *z_d
 int qgx_cnn_forward(qgx_generator *g, int inet, const float *x_dev, float *y_dev,
                     int B, int N, void *stream);
 
+/* Measurement hook (bench.py roofline leg; no reference counterpart): bracket every launch of
+ * conv layer `layer` (0..7, -1 = off) of every net with HIP events on the launch stream;
+ * _read synchronises those events, returns their summed duration and the launch count, and
+ * clears the record. */
+int qgx_generator_profile(qgx_generator *g, int layer);
+int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches);
+
 /* ---- latent noise ------------------------------------------------------------
  * z <- a z + b xi with xi ~ N(0,1) from Philox4x32-10 (stochastic_pyqg.py:43-49). */
 int qgx_noise_normal(void *z_dev, int is_double, int B, int n_per_member, uint64_t seed,

@@ -279,6 +279,10 @@ struct qgx_generator {
     // workspace (grown on demand, outside any captured region)
     size_t cap_elems = 0;          // capacity in units of B*N*N pixels
     float *actA = nullptr, *actB = nullptr, *X = nullptr, *Y0 = nullptr, *Y1 = nullptr;
+    // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
+    int prof_layer = -1;
+    std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
+    size_t prof_used = 0;
 };
 
 namespace qgx {
@@ -336,9 +340,27 @@ static int choose_rows(int N) {
     return 0;
 }
 
+static int prof_begin(qgx_generator *g, int layer, hipStream_t st, hipEvent_t &stop) {
+    stop = nullptr;
+    if (g->prof_layer != layer) return QGX_OK;
+    if (g->prof_used + 2 > g->prof_ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            QGX_HIP(hipEventCreate(&e));
+            g->prof_ev.push_back(e);
+        }
+    }
+    QGX_HIP(hipEventRecord(g->prof_ev[g->prof_used], st));
+    stop = g->prof_ev[g->prof_used + 1];
+    g->prof_used += 2;
+    return QGX_OK;
+}
+
 template <int CIN, int COUT, int KS, int CC, bool PLANAR_IN, bool FINAL>
-static int launch_conv(const LayerHost &L, const float *in, float *out, int B, int N, int cout_real,
-                       hipStream_t st) {
+static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
+                       int N, int cout_real, hipStream_t st) {
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
     const int R = choose_rows(N);
     QGX_REQUIRE(R > 0 && N % R == 0, "generator: unsupported grid size N=%d", N);
     const int ntiles = R * N / 32;
@@ -359,6 +381,7 @@ static int launch_conv(const LayerHost &L, const float *in, float *out, int B, i
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     }
     QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
 }
 
@@ -366,7 +389,7 @@ static int reserve(qgx_generator *g, int B, int N) {
     const size_t need = (size_t)B * N * N;
     if (need <= g->cap_elems) return QGX_OK;
     float **bufs[] = {&g->actA, &g->actB, &g->X, &g->Y0, &g->Y1};
-    for (auto p : bufs) if (*p) { hipFree(*p); *p = nullptr; }
+    for (auto p : bufs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     g->cap_elems = 0;
     QGX_HIP(hipMalloc((void **)&g->actA, need * 128 * sizeof(float)));
     QGX_HIP(hipMalloc((void **)&g->actB, need * 64 * sizeof(float)));
@@ -382,16 +405,16 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
                        hipStream_t st) {
     int rc;
     float *A = g->actA, *Bb = g->actB;
-    if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false>(net.L[0], x, A, B, N, 128, st);
-    else rc = launch_conv<2, 128, 5, 2, true, false>(net.L[0], x, A, B, N, 128, st);
+    if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false>(g, 0, net.L[0], x, A, B, N, 128, st);
+    else rc = launch_conv<2, 128, 5, 2, true, false>(g, 0, net.L[0], x, A, B, N, 128, st);
     if (rc) return rc;
-    if ((rc = launch_conv<128, 64, 5, 32, false, false>(net.L[1], A, Bb, B, N, 64, st))) return rc;
-    if ((rc = launch_conv<64, 32, 3, 32, false, false>(net.L[2], Bb, A, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(net.L[3], A, Bb, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(net.L[4], Bb, A, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(net.L[5], A, Bb, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(net.L[6], Bb, A, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 2, 3, 32, false, true>(net.L[7], A, y, B, N, net.n_out, st))) return rc;
+    if ((rc = launch_conv<128, 64, 5, 32, false, false>(g, 1, net.L[1], A, Bb, B, N, 64, st))) return rc;
+    if ((rc = launch_conv<64, 32, 3, 32, false, false>(g, 2, net.L[2], Bb, A, B, N, 32, st))) return rc;
+    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 3, net.L[3], A, Bb, B, N, 32, st))) return rc;
+    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 4, net.L[4], Bb, A, B, N, 32, st))) return rc;
+    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 5, net.L[5], A, Bb, B, N, 32, st))) return rc;
+    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 6, net.L[6], Bb, A, B, N, 32, st))) return rc;
+    if ((rc = launch_conv<32, 2, 3, 32, false, true>(g, 7, net.L[7], A, y, B, N, net.n_out, st))) return rc;
     return QGX_OK;
 }
 
@@ -460,15 +483,16 @@ extern "C" int qgx_generator_create(int kind, const qgx_cnn_weights *nets, int n
 
 extern "C" int qgx_generator_destroy(qgx_generator *g) {
     if (!g) return QGX_OK;
-    hipSetDevice(g->device);
+    (void)hipSetDevice(g->device);
     for (int n = 0; n < 2; ++n)
         for (int li = 0; li < 8; ++li) {
             LayerHost &L = g->nets[n].L[li];
             float *ptrs[] = {L.w, L.bias, L.scale, L.shift};
-            for (float *p : ptrs) if (p) hipFree(p);
+            for (float *p : ptrs) if (p) (void)hipFree(p);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1};
-    for (float *p : bufs) if (p) hipFree(p);
+    for (float *p : bufs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     delete g;
     return QGX_OK;
 }
@@ -484,4 +508,26 @@ extern "C" int qgx_cnn_forward(qgx_generator *g, int inet, const float *x_dev, f
     int rc = reserve(g, B, N);
     if (rc) return rc;
     return cnn_forward(g, g->nets[inet], x_dev, y_dev, B, N, (hipStream_t)stream);
+}
+
+extern "C" int qgx_generator_profile(qgx_generator *g, int layer) {
+    QGX_REQUIRE(g && layer >= -1 && layer < 8, "qgx_generator_profile: bad argument");
+    g->prof_layer = layer;
+    g->prof_used = 0;
+    return QGX_OK;
+}
+
+extern "C" int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches) {
+    QGX_REQUIRE(g && total_ms && launches, "qgx_generator_profile_read: null argument");
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < g->prof_used; i += 2) {
+        QGX_HIP(hipEventSynchronize(g->prof_ev[i + 1]));
+        float ms = 0.f;
+        QGX_HIP(hipEventElapsedTime(&ms, g->prof_ev[i], g->prof_ev[i + 1]));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)(g->prof_used / 2);
+    g->prof_used = 0;
+    return QGX_OK;
 }

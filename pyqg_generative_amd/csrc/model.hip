@@ -223,8 +223,8 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
             qgx_destroy(m);
             return QGX_ERR_HIP;
         }
-        hipMemset(p, 0, nr * sizeof(double));
-        hipMemset(p2, 0, nr * sizeof(double));
+        (void)hipMemset(p, 0, nr * sizeof(double));
+        (void)hipMemset(p2, 0, nr * sizeof(double));
         m->z = p; m->xi = p2;
     }
     m->small = small_path_fits(N);
@@ -240,11 +240,11 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
 
 extern "C" int qgx_destroy(qgx_model *m) {
     if (!m) return QGX_OK;
-    hipSetDevice(m->cfg.device);
+    (void)hipSetDevice(m->cfg.device);
     void *ptrs[] = {m->t_filtr, m->t_wv2, m->t_a, m->t_kk, m->t_ll, m->t_tw, m->t_pos, m->q, m->u, m->v,
                     m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->zbuf,
                     m->z, m->xi};
-    for (void *p : ptrs) if (p) hipFree(p);
+    for (void *p : ptrs) if (p) (void)hipFree(p);
     delete m;
     return QGX_OK;
 }

@@ -80,6 +80,16 @@ class Generator:
         check(lib.qgx_cnn_forward(self._h, inet, _ptr(x), _ptr(y), B, N, _stream()))
         return y
 
+    def profile(self, layer):
+        """Bracket every launch of conv layer `layer` (0..7; -1 = off) with HIP events."""
+        check(lib.qgx_generator_profile(self._h, int(layer)))
+
+    def profile_read(self):
+        """-> (summed kernel milliseconds, launches) since the last read."""
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(lib.qgx_generator_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def close(self):
         if self._h:
             lib.qgx_generator_destroy(self._h)
