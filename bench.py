@@ -161,6 +161,16 @@ def main():
         flop_per_launch = 2.0 * MAC_PER_PIXEL[1] * N * N * B
         avg_s = (l2_ms / max(l2_n, 1)) * 1e-3
         achieved = flop_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
+        # HBM traffic of that kernel cannot be measured from inside this process: it comes from
+        # the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+                pt = json.load(f)
+            if pt['config'] == {'nx': N, 'members_per_gpu': B, 'kind': args.kind}:
+                traffic = pt['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            pass
         gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
         out = {
             'metric': 'ensemble-timesteps/sec, 64^2 2-layer eddy + GAN param',
@@ -175,7 +185,7 @@ def main():
                        'parallelism': f'ensemble-sharded x{world}, no data-path collective'},
             'roofline': {'bound': 'mfma', 'kernel': 'k_conv<128,64,5x5> (generator layer 2)',
                          'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_s * 1e3,
                          'launches_timed': l2_n,
                          'whole_step_generator_tflops': gen_flop_per_member_step * value / world / 1e12},
