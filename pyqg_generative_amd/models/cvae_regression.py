@@ -1,0 +1,14 @@
+"""CVAE decoder parameterization, inference surface of
+pyqg_generative/models/cvae_regression.py (:18-52 constructor, :114-118 generate,
+:128-145 generate_latent_noise / predict_snapshot / predict_mean_snapshot)."""
+from .cgan_regression import _LatentCNN
+
+
+class CVAERegression(_LatentCNN):
+    kind = 'vae'
+
+    def __init__(self, regression='None', folder='model', div=False, decoder_var='adaptive', device=0, **kw):
+        if regression != 'None' or div:
+            raise NotImplementedError('only regression="None", div=False has a device path')
+        self.regression, self.div, self.decoder_var = regression, div, decoder_var
+        self._load(folder, device)          # needs decoder.pt (the encoder is training-only)

@@ -1,0 +1,24 @@
+"""Guillaumin-Zanna mean/variance parameterization, inference surface of
+pyqg_generative/models/mean_var_model.py (:14-17 VarCNN softplus, :24-39 constructor,
+:102-115 generate_latent_noise / predict_snapshot / predict_mean_snapshot)."""
+import numpy as np
+
+from .parameterization import Parameterization
+from ..tools.cnn_tools import apply_function
+
+
+class MeanVarModel(Parameterization):
+    kind = 'gz'
+
+    def __init__(self, folder='model', hidden_channels=[128, 64, 32, 32, 32, 32, 32], device=0):
+        if list(hidden_channels) != [128, 64, 32, 32, 32, 32, 32]:
+            raise NotImplementedError('only the shipped channel configuration has a device path')
+        self.hidden_channels = hidden_channels
+        self._load(folder, device)          # needs net_mean.pt and net_var.pt
+
+    def generate_latent_noise(self, ny, nx):
+        return np.random.randn(2, ny, nx)
+
+    def predict_mean_snapshot(self, m, M=100):
+        X = self.x_scale.normalize(np.asarray(m.q, 'float64').astype('float32'))
+        return self.y_scale.denormalize(apply_function(self._gen, X, inet=0)).squeeze().astype('float64')

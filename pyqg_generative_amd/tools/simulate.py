@@ -1,0 +1,103 @@
+"""Online stepper: builds the model, sets the initial condition, drives the snapshot loop
+(reference: pyqg_generative/tools/simulate.py:16-60 drop_vars / concat_in_time, :109-145
+run_simulation, :147-168 set_initial_condition).
+
+Ensemble extension: ``n_members`` members advance together on one GPU; datasets gain a
+leading 'run' dimension (the reference's name for the member axis, simulate.py:284) when
+n_members > 1.
+"""
+import numpy as np
+
+from ..qgmodel import QGModel
+from .parameters import ANDREW_1000_STEPS
+from .stochastic_pyqg import stochastic_QGModel
+
+
+def dataset_backend():
+    try:
+        import xarray as xr
+        return xr
+    except ImportError:
+        from . import xr_lite
+        return xr_lite
+
+
+def set_initial_condition(m, seeds=None):
+    """Band-limited random PV in the upper layer (power confined to the scales a 32x32 model
+    resolves), zero in the lower layer; then m._invert().
+
+    seeds: None -> numpy's global stream, exactly the reference's draw order (rand(ny,nx) then
+    rand(1,nx), per member); else one integer seed per member (seed = member id).
+    """
+    B = getattr(m, 'n_members', 1)
+    q = np.zeros((B, 2, m.ny, m.nx))
+    for b in range(B):
+        rng = np.random if seeds is None else np.random.RandomState(int(seeds[b]))
+        q2d = 1e-7 * rng.rand(m.ny, m.nx)
+        q2d -= q2d.mean(axis=(-2, -1), keepdims=True)
+        q2d *= np.sqrt(m.nx * m.ny / 64 ** 2)
+        q1d = 1e-6 * (np.ones((m.ny, 1)) * rng.rand(1, m.nx))
+        q1d -= q1d.mean(axis=(-2, -1), keepdims=True)
+        q1d *= np.sqrt(m.nx / 64)
+        Xf = np.fft.rfftn(q1d + q2d)
+        q[b, 0] = np.fft.irfftn(Xf * (m.wv < np.pi / (m.L / 32)))
+    m.q = q[0] if B == 1 else q
+    m._invert()
+
+
+def snapshot_dataset(m):
+    """The part of pyqg's Model.to_dataset() that survives drop_vars: q, u, v, psi as float32
+    (time, [run,] lev, y, x) with pyqg's coordinates; time in days."""
+    xr = dataset_backend()
+    B = m.n_members
+    lead = ('time',) if B == 1 else ('time', 'run')
+    dims = lead + ('lev', 'y', 'x')
+    f32 = lambda a: np.asarray(a, dtype='float32')[None]
+    data = {'q': (dims, f32(m.q)), 'u': (dims, f32(m.u)), 'v': (dims, f32(m.v)), 'psi': (dims, f32(m.p))}
+    coords = {'time': ('time', np.array([m.t / 86400.], dtype='float32')),
+              'lev': ('lev', np.arange(1, 3)),
+              'x': ('x', m.x[0, :].astype('float32')), 'y': ('y', m.y[:, 0].astype('float32'))}
+    if B > 1:
+        coords['run'] = ('run', np.arange(m.member_offset, m.member_offset + B))
+    if xr.__name__.endswith('xr_lite'):
+        ds = xr.Dataset(data, coords={k: xr.DataArray(v[1], [v[0]]) for k, v in coords.items()})
+    else:
+        ds = xr.Dataset({k: (v[0], v[1]) for k, v in data.items()}, coords=coords)
+    ds['time'].attrs['units'] = 'days'
+    ds.attrs.update({'pyqg:nx': m.nx, 'pyqg:dt': m.dt, 'pyqg:rek': m.rek, 'pyqg:delta': m.delta,
+                     'pyqg:beta': m.beta, 'pyqg:L': m.L, 'pyqg:rd': m.rd})
+    return ds
+
+
+def concat_in_time(datasets):
+    xr = dataset_backend()
+    return xr.concat(datasets, dim='time')
+
+
+def run_simulation(pyqg_params, parameterization=None, q_init=None, sampling_freq=ANDREW_1000_STEPS,
+                   n_members=1, seeds=None, device=0, seed=0, member_offset=0):
+    """pyqg_params: dict of model parameters; parameterization: None or
+    dict(self=<Parameterization>, sampling='AR1'|'constant'|'deterministic', nsteps=int);
+    q_init: optional PV (nlev,ny,nx) or (B,nlev,ny,nx).  Returns a Dataset of snapshots taken
+    every ``sampling_freq`` seconds of model time."""
+    params = dict(pyqg_params)
+    params['tmax'] = float(params['tmax'])
+    eng = dict(n_members=n_members, device=device, seed=seed, member_offset=member_offset)
+    if parameterization is None:
+        m = QGModel(**params, **eng)
+    else:
+        params['parameterization'] = parameterization['self']
+        m = stochastic_QGModel(params, parameterization['sampling'], parameterization['nsteps'], **eng)
+    if q_init is not None:
+        m.q = np.asarray(q_init, dtype='float64')
+        m._invert()
+        parts = [snapshot_dataset(m)]            # convenient to have the IC saved
+    else:
+        set_initial_condition(m, seeds)
+        parts = []
+    for _ in m.run_with_snapshots(tsnapint=sampling_freq):
+        parts.append(snapshot_dataset(m))
+    ds = concat_in_time(parts)
+    ds.attrs['pyqg_params'] = str(pyqg_params)
+    m.close()
+    return ds

@@ -1,0 +1,45 @@
+"""CPU, world_size 2, gloo: the N>1 path = contiguous member shards + ONE all-reduce of partial
+spectral sums for the ensemble mean; no other exchange exists on the path."""
+import os
+import sys
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, total, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from pyqg_generative_amd import parallel
+    dist = parallel.init_process_group('gloo')
+    first, n = parallel.shard_members(total, rank, world)
+    # synthetic per-member spectra, a deterministic function of the GLOBAL member id
+    spec = torch.stack([torch.full((2, 8, 5), float(mid)) + torch.arange(5.) for mid in range(first, first + n)]) \
+        if n else torch.zeros((0, 2, 8, 5))
+    mean = parallel.ensemble_mean(spec.sum(0).to(torch.float64), n)
+    np.save(os.path.join(tmp, f'mean{rank}.npy'), mean.numpy())
+    np.save(os.path.join(tmp, f'ids{rank}.npy'), np.arange(first, first + n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ensemble_mean(tmp_path):
+    total, world, port = 7, 2, 29611
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    ids = np.concatenate([np.load(tmp_path / f'ids{r}.npy') for r in range(world)])
+    assert sorted(ids.tolist()) == list(range(total))
+    expect = np.mean(np.arange(total)) + np.arange(5.)
+    for r in range(world):
+        m = np.load(tmp_path / f'mean{r}.npy')
+        assert m.shape == (2, 8, 5)
+        np.testing.assert_allclose(m, np.broadcast_to(expect, (2, 8, 5)), rtol=1e-14)
+
+
+def test_single_process_ensemble_mean_is_local_mean():
+    sys.path.insert(0, ROOT)
+    from pyqg_generative_amd import parallel
+    x = torch.arange(24, dtype=torch.float64).reshape(2, 3, 4)
+    np.testing.assert_allclose(parallel.ensemble_mean(x * 5, 5).numpy(), x.numpy())
