@@ -47,7 +47,7 @@ def _eddy_like_q(rs, B, N):
     return np.fft.irfftn(qh, axes=(-2, -1)) * 3.0
 
 
-@pytest.mark.parametrize('N', [32, 48, 64, 96])
+@pytest.mark.parametrize('N', [32, 48, 64, 96, 128, 192, 256])
 def test_q_qh_roundtrip_and_invert(N):
     import pyqg_generative_amd._lib as L
     B = 3
@@ -81,11 +81,12 @@ def test_q_qh_roundtrip_and_invert(N):
 
 @pytest.mark.parametrize('N,params', [(64, dict(dt=14400.)), (48, dict(dt=14400.)),
                                       (96, dict(dt=7200., rek=7e-8, delta=0.1, beta=1e-11)),
-                                      (32, dict(dt=14400.))])
+                                      (32, dict(dt=14400.)), (128, dict(dt=7200.)),
+                                      (256, dict(dt=3600.)), (384, dict(dt=3600.))])
 def test_unparameterized_steps_match_oracle(N, params):
     """configs[0] physics on the GPU: Euler -> AB2 -> AB3 start-up, filter, friction."""
     import pyqg_generative_amd._lib as L
-    B, nsteps = 3, 12
+    B, nsteps = (3, 12) if N <= 128 else (2, 6)
     rs = np.random.RandomState(100 + N)
     q0 = _eddy_like_q(rs, B, N)
     e = _engine(N, B, **params)
