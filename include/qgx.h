@@ -159,6 +159,26 @@ int qgx_generator_forward(qgx_generator *g, const double *q_dev, const void *z_d
 int qgx_cnn_forward(qgx_generator *g, int inet, const float *x_dev, float *y_dev,
                     int B, int N, void *stream);
 
+/* ---- coarse-graining / re-gridding building blocks ----------------------------------------
+ * The reference's operators (tools/operators.py:84-99,117-217,241-268) are compositions of these.
+ * A model handle doubles as the FFT plan of its grid: fields are (B,2,N,N) / (B,2,N,N/2+1). */
+/* numpy-compatible rfft2 / irfft2 of the model's grid; does not touch the model state
+ * (pyqg m.fft / m.ifft, operators.py:244-246). */
+int qgx_rfft2(qgx_model *m, const double *x_dev, double *xh_dev, void *stream);
+int qgx_irfft2(qgx_model *m, const double *xh_dev, double *x_dev, void *stream);
+/* dst (nfields,N,N/2+1) <- scale * filter * [resolved block of src (nfields,n,n/2+1)]: the mode
+ * transfer of cut_off (operators.py:123-130) and fft_interpolate (:148-189); zero_src_2h zeroes
+ * src[h,0] first, zero_dst_2h zeroes dst[h,0] and dst[:,h] (h = min(n,N)/2); filter_dev is an
+ * optional real (N,N/2+1) table on the destination grid (gauss_filter :87-90, model_filter :97-99). */
+int qgx_spec_regrid(const double *src_dev, double *dst_dev, int nfields, int n, int N, double scale,
+                    int zero_src_2h, int zero_dst_2h, const double *filter_dev, void *stream);
+/* out = ik*A + il*B on an N-grid of domain size L (divergence, operators.py:241-247); A or B may be NULL */
+int qgx_spec_div(const double *ah_dev, const double *bh_dev, double *out_dev, int nfields, int N,
+                 double L, void *stream);
+/* out = alpha * a * b + beta * c  (b, c optional): the pointwise products of advect (:258-266) */
+int qgx_real_fma(const double *a_dev, const double *b_dev, double *out_dev, size_t n, double alpha,
+                 const double *c_dev, double beta, void *stream);
+
 /* Measurement hook (bench.py roofline leg; no reference counterpart): bracket every launch of
  * conv layer `layer` (0..7, -1 = off) of every net with HIP events on the launch stream;
  * _read synchronises those events, returns their summed duration and the launch count, and

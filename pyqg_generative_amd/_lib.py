@@ -65,6 +65,13 @@ SYMBOLS = [
                                         C.c_int, C.c_int, C.c_void_p]),
     ('qgx_cnn_forward', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                   C.c_void_p]),
+    ('qgx_rfft2', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('qgx_irfft2', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('qgx_spec_regrid', C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                  C.c_int, C.c_void_p, C.c_void_p]),
+    ('qgx_spec_div', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
+    ('qgx_real_fma', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p,
+                               C.c_double, C.c_void_p]),
     ('qgx_generator_profile', C.c_int, [C.c_void_p, C.c_int]),
     ('qgx_generator_profile_read', C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ('qgx_noise_normal', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,

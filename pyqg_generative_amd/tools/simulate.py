@@ -101,3 +101,49 @@ def run_simulation(pyqg_params, parameterization=None, q_init=None, sampling_fre
     ds.attrs['pyqg_params'] = str(pyqg_params)
     m.close()
     return ds
+
+
+def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n_members=1, seeds=None,
+                             device=0, operators=('Operator2', 'Operator5')):
+    """Forcing-dataset generation (reference: simulate.py:62-106): run the high-resolution model given
+    by pyqg_params and, every ``sampling_freq`` seconds, coarse-grain the PV to each resolution in Nc
+    with each operator and diagnose the subgrid forcing with 3/2-rule dealiasing.  Returns
+    {'<Operator>-<nc>-dealias': Dataset(q_forcing_advection, q, u, v, psi  float32 (time,[run,]lev,y,x))}.
+    The hires members, the coarse-graining and the forcing diagnostic all stay on the GPU."""
+    import torch
+    from .operators import Dev
+    from .. import _lib
+    xr = dataset_backend()
+    params = dict(pyqg_params)
+    params['tmax'] = float(params['tmax'])
+    m = QGModel(**params, n_members=n_members, device=device)
+    set_initial_condition(m, seeds)
+    coarse_params = {k: v for k, v in params.items() if k in ('rek', 'delta', 'beta', 'rd', 'U1', 'U2', 'H1', 'L')}
+    B = n_members
+    lead = ('time',) if B == 1 else ('time', 'run')
+    dims = lead + ('lev', 'y', 'x')
+    out = {}
+    for _ in m.run_with_snapshots(tsnapint=sampling_freq):
+        qd = m.q_device()
+        for opname in operators:
+            dev_op = getattr(Dev, opname)
+            for nc in Nc:
+                forcing, qf, uf, vf = Dev.PV_subgrid_forcing(qd, nc, dev_op, coarse_params, '3/2-rule')
+                plan = Dev._plans[next(k for k in Dev._plans if k[0] == 'inv' and k[1] == nc and k[2] == B)]
+                ph = plan.get(_lib.F_PH).reshape(-1, nc, nc // 2 + 1)
+                psi = Dev.irfft2(ph).reshape(B, 2, nc, nc)
+                pack = lambda t: (t[0] if B == 1 else t).to(torch.float32).cpu().numpy()[None]
+                data = {'q_forcing_advection': (dims, pack(forcing)), 'q': (dims, pack(qf)),
+                        'u': (dims, pack(uf)), 'v': (dims, pack(vf)), 'psi': (dims, pack(psi))}
+                xc = ((np.arange(nc) + 0.5) / nc * m.L).astype('float32')
+                coords = {'time': np.array([m.t / 86400.], dtype='float32'), 'lev': np.arange(1, 3), 'x': xc, 'y': xc}
+                if xr.__name__.endswith('xr_lite'):
+                    ds = xr.Dataset(data, coords={k: xr.DataArray(v, [k]) for k, v in coords.items()})
+                else:
+                    ds = xr.Dataset(data, coords={k: (k, v) for k, v in coords.items()})
+                ds['time'].attrs['units'] = 'days'
+                out.setdefault(f'{opname}-{nc}-dealias', []).append(ds)
+    for key in out:
+        out[key] = xr.concat(out[key], 'time').assign_attrs({'pyqg_params': str(pyqg_params)})
+    m.close()
+    return out
