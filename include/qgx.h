@@ -132,6 +132,25 @@ int qgx_reset_time(qgx_model *m);
 /* status reductions of pyqg's _print_status: out_dev[2*b+0] = KE, [2*b+1] = CFL */
 int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream);
 
+/* ---- time-averaged spectral diagnostics ------------------------------------------------
+ * pyqg model.py::_calc_diagnostics / _increment_diagnostics; consumed by the reference in
+ * tools/comparison_tools.py:91-188.  Accumulated inside qgx_step before every step with
+ * tc >= start_step and tc % every == 0 (pyqg: t >= tavestart, tc % ceil(taveint/dt) == 0). */
+enum qgx_diag {              /* per member; pyqg normalisation 1/M^2 */
+    QGX_D_KESPEC = 0,        /* (B,2,N,N/2+1)  wv2 |ph|^2                         */
+    QGX_D_ENSSPEC = 1,       /* (B,2,N,N/2+1)  |qh|^2                             */
+    QGX_D_ENTSPEC = 2,       /* (B,N,N/2+1)    |del1 qh1 + del2 qh2|^2            */
+    QGX_D_APEFLUX = 3,       /* (B,N,N/2+1)                                       */
+    QGX_D_KEFLUX = 4,
+    QGX_D_APEGENSPEC = 5,
+    QGX_D_KEFRICTIONSPEC = 6,
+    QGX_D_PARAMSPEC = 7
+};
+int qgx_diag_config(qgx_model *m, int64_t start_step, int every);   /* every <= 0 disables */
+int qgx_diag_get(qgx_model *m, int diag, double *out_dev, void *stream);   /* time mean */
+int64_t qgx_diag_count(const qgx_model *m);
+int qgx_diag_reset(qgx_model *m);
+
 /* ---- generator ---------------------------------------------------------------
  * Replaces AndrewCNN inference through apply_function (cnn_tools.py:125-176,
  * 702-735) for CGANRegression.G / CVAERegression.decoder / MeanVarModel nets. */
@@ -183,6 +202,9 @@ int qgx_real_fma(const double *a_dev, const double *b_dev, double *out_dev, size
  * conv layer `layer` (0..7, -1 = off) of every net with HIP events on the launch stream;
  * _read synchronises those events, returns their summed duration and the launch count, and
  * clears the record. */
+/* kernel-variant switches for in-process A/B measurement: "chunk" (16|32 input channels staged per
+ * pass), "stage_batched" (0|1), "persistent" (0|1: loader-wave LDS-DMA variant). */
+int qgx_generator_set_option(qgx_generator *g, const char *name, int value);
 int qgx_generator_profile(qgx_generator *g, int layer);
 int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches);
 

@@ -41,6 +41,7 @@ class qgx_cnn_weights(C.Structure):
 F_Q, F_QH, F_PH, F_U, F_V, F_DQHDT, F_DQHDT_P, F_DQHDT_PP, F_S, F_Z = range(10)
 T_FILTR, T_WV2, T_A, T_KK, T_LL = range(5)
 SAMPLING_AR1, SAMPLING_CONSTANT = 0, 1
+DIAGS = ['KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec', 'paramspec']
 GEN_GAN, GEN_VAE, GEN_GZ = 0, 1, 2
 
 # every symbol include/qgx.h declares: (name, restype, argtypes)
@@ -57,6 +58,10 @@ SYMBOLS = [
     ('qgx_step_count', C.c_int64, [C.c_void_p]),
     ('qgx_reset_time', C.c_int, [C.c_void_p]),
     ('qgx_status_ke_cfl', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ('qgx_diag_config', C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    ('qgx_diag_get', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    ('qgx_diag_count', C.c_int64, [C.c_void_p]),
+    ('qgx_diag_reset', C.c_int, [C.c_void_p]),
     ('qgx_generator_create', C.c_int, [C.c_int, C.POINTER(qgx_cnn_weights), C.c_int,
                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                        C.POINTER(C.c_void_p)]),
@@ -72,6 +77,7 @@ SYMBOLS = [
     ('qgx_spec_div', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     ('qgx_real_fma', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p,
                                C.c_double, C.c_void_p]),
+    ('qgx_generator_set_option', C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ('qgx_generator_profile', C.c_int, [C.c_void_p, C.c_int]),
     ('qgx_generator_profile_read', C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ('qgx_noise_normal', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,

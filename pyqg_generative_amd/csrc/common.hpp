@@ -94,6 +94,12 @@ struct qgx_model {
     int64_t tc = 0;
     int ablevel = 0;
     uint64_t noise_step = 0;
+    // time-averaged diagnostics (diag.hip)
+    int64_t dg_start = 0, dg_count = 0;
+    int dg_every = 0;
+    double *dg_R[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *dg_S[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *dg_acc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace qgx {
@@ -101,6 +107,7 @@ namespace qgx {
 int generator_forward(qgx_generator *g, const double *q, const void *z, double *S, int B, int N,
                       int demean, hipStream_t st);
 bool generator_noise_is_double(const qgx_generator *g);
+int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st);
 int noise_update(void *z, const void *xi_ext, bool is_double, int B, int n_per_member, uint64_t seed,
                  uint64_t member_offset, uint64_t step, double a, double b, hipStream_t st);
 int noise_normal(void *z, bool is_double, int B, int n_per_member, uint64_t seed,

@@ -36,7 +36,7 @@ struct ConvArgs {
 
 extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
-template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL>
+template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL, int SM = 0>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     constexpr int NT = (COUT + 31) / 32;
     constexpr int COUTP = NT * 32;
@@ -73,13 +73,34 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 
     if constexpr (PLANAR_IN) {
         // ---- stage the whole (tiny) input patch: patch[(pr*N + x)*CIN + c]
-        for (int it = threadIdx.x; it < PR * CIN * N; it += 256) {
-            const int x = it % N;
-            const int c = (it / N) % CIN;
-            const int pr = it / (N * CIN);
-            int gy = y0 - P + pr;
-            gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
-            patch[(pr * N + x) * CIN + c] = a.in[(((size_t)b * CIN + c) * N + gy) * N + x];
+        // (loads are issued in batches of 8 before any LDS store so that their latencies overlap)
+        {
+            const int total = PR * CIN * N;
+            for (int base = 0; base < total; base += 256 * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = base + u * 256 + threadIdx.x;
+                    if (it < total) {
+                        const int x = it % N;
+                        const int c = (it / N) % CIN;
+                        const int pr = it / (N * CIN);
+                        int gy = y0 - P + pr;
+                        gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+                        v[u] = a.in[(((size_t)b * CIN + c) * N + gy) * N + x];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = base + u * 256 + threadIdx.x;
+                    if (it < total) {
+                        const int x = it % N;
+                        const int c = (it / N) % CIN;
+                        const int pr = it / (N * CIN);
+                        patch[(pr * N + x) * CIN + c] = v[u];
+                    }
+                }
+            }
         }
         __syncthreads();
         constexpr int NG = (T * CIN + 7) / 8;
@@ -127,45 +148,124 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         for (int c0 = 0; c0 < CIN; c0 += CC) {
             __syncthreads();
             // ---- stage patch chunk: (PR rows) x N x CC channels, pixel stride CC+4 floats
-            for (int it = threadIdx.x; it < PR * N * C4; it += 256) {
-                const int c4 = it % C4;
-                const int x = (it / C4) % N;
-                const int pr = it / (C4 * N);
-                int gy = y0 - P + pr;
-                gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
-                const float4 vv = *reinterpret_cast<const float4 *>(
-                    &a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
-                *reinterpret_cast<float4 *>(&patch[(pr * N + x) * STRIDE + c4 * 4]) = vv;
-            }
-            __syncthreads();
-            for (int ky = 0; ky < KS; ++ky)
-                for (int kx = 0; kx < KS; ++kx) {
-                    int aoff[MT];
+            if constexpr (SM == 2) {
+                // ablation: no staging traffic
+            } else if constexpr (SM == 0 || SM >= 3) {
+                for (int it = threadIdx.x; it < PR * N * C4; it += 256) {
+                    const int c4 = it % C4;
+                    const int x = (it / C4) % N;
+                    const int pr = it / (C4 * N);
+                    int gy = y0 - P + pr;
+                    gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+                    const float4 vv = *reinterpret_cast<const float4 *>(
+                        &a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
+                    *reinterpret_cast<float4 *>(&patch[(pr * N + x) * STRIDE + c4 * 4]) = vv;
+                }
+            } else {
+            // All loads of a batch are in flight before the first LDS store (a load->store pair per
+            // iteration would serialise 8-16 HBM/L2 latencies per stage).
+            {
+                const int total = PR * N * C4;
+                for (int base = 0; base < total; base += 256 * 8) {
+                    float4 v[8];
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        int col = px[mt] + kx - P;
-                        col = col < 0 ? col + N : (col >= N ? col - N : col);
-                        aoff[mt] = ((py[mt] + ky) * N + col) * STRIDE + 4 * h;
+                    for (int u = 0; u < 8; ++u) {
+                        const int it = base + u * 256 + threadIdx.x;
+                        if (it < total) {
+                            const int c4 = it % C4;
+                            const int pl = it / C4;
+                            const int pr = pl / N, x = pl - pr * N;
+                            int gy = y0 - P + pr;
+                            gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+                            v[u] = *reinterpret_cast<const float4 *>(
+                                &a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
+                        }
                     }
 #pragma unroll
-                    for (int g8 = 0; g8 < G8; ++g8) {
-                        float4 A[MT], Bf[NT];
+                    for (int u = 0; u < 8; ++u) {
+                        const int it = base + u * 256 + threadIdx.x;
+                        if (it < total) {
+                            const int c4 = it % C4;
+                            const int pl = it / C4;
+                            *reinterpret_cast<float4 *>(&patch[pl * STRIDE + c4 * 4]) = v[u];
+                        }
+                    }
+                }
+            }
+                        }
+            __syncthreads();
+            // ---- K loop over (tap, 8-channel group), software pipelined: the A fragment (LDS) and the
+            // B fragment (packed weights, L2) of step i+1 are requested before the MFMAs of step i.
+            int ky = 0, kx = 0;
+            int aoff[MT];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) Bf[nt] = wp[((size_t)g8 * COUTP + nt * 32) * 2];
+            for (int mt = 0; mt < MT; ++mt) {
+                int col = px[mt] - P;
+                col = col < 0 ? col + N : col;
+                aoff[mt] = (py[mt] * N + col) * STRIDE + 4 * h;
+            }
+            float4 An[MT], Bn[NT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            A[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt] + g8 * 8]);
+            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[(size_t)nt * 64];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+            for (int mt = 0; mt < MT; ++mt) An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt]]);
+            for (int tap = 0; tap < T; ++tap) {
+                const bool last_tap = tap == T - 1;
+                int nkx = kx + 1, nky = ky;
+                if (nkx == KS) { nkx = 0; ++nky; }
+                int aoff_n[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    int col = px[mt] + nkx - P;
+                    col = col < 0 ? col + N : (col >= N ? col - N : col);
+                    aoff_n[mt] = last_tap ? aoff[mt] : ((py[mt] + nky) * N + col) * STRIDE + 4 * h;
+                }
+                const float4 *wp_n = last_tap ? wp : wp + (size_t)G8 * COUTP * 2;
+#pragma unroll
+                for (int g8 = 0; g8 < G8; ++g8) {
+                    float4 A[MT], Bf[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) A[mt] = An[mt];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) Bf[nt] = Bn[nt];
+                    if (g8 + 1 < G8) {
+                        if constexpr (SM != 3 && SM != 5) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[((size_t)(g8 + 1) * COUTP + nt * 32) * 2];
+                        }
+                        if constexpr (SM != 4 && SM != 5) {
 #pragma unroll
                             for (int mt = 0; mt < MT; ++mt)
+                                An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt] + (g8 + 1) * 8]);
+                        }
+                    } else {
+                        if constexpr (SM != 3 && SM != 5) {
 #pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                        (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
+                            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp_n[(size_t)nt * 64];
+                        }
+                        if constexpr (SM != 4 && SM != 5) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff_n[mt]]);
+                        }
                     }
-                    wp += (size_t)G8 * COUTP * 2;
+                    // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks the loads to their use)
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
                 }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) aoff[mt] = aoff_n[mt];
+                wp = wp_n;
+                kx = nkx; ky = nky;
+            }
+            wp += (size_t)G8 * COUTP * 2;      // the last tap did not advance
         }
     }
 
@@ -199,6 +299,185 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
                 }
             }
         }
+    }
+}
+
+// ---- persistent, double-buffered variant ------------------------------------------------------
+// Same tiling and MFMA mapping as k_conv, but (a) the workgroup is persistent and walks over its
+// tiles, (b) a fifth "loader" wave streams the NEXT (tile, channel-chunk) patch global -> LDS with
+// LDS-DMA (global_load_lds_dwordx4: no VGPR staging, its own vmcnt queue) into the second of two
+// buffers while the four MFMA waves consume the current one; one barrier per stage.
+// LDS-DMA writes 1 KiB per wave-instruction linearly (8 pixels x 32 channels), so the patch is
+// unpadded [pixel][32 floats] and bank conflicts are removed by XOR-swizzling the 16-byte slot
+// with (pixel >> 1) & 7 on the SOURCE address and again on the A-fragment read.
+template <int CIN, int COUT, int KS, int MT>
+__global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
+    constexpr int CC = 32;
+    constexpr int NT = (COUT + 31) / 32;
+    constexpr int COUTP = NT * 32;
+    constexpr int P = KS / 2;
+    constexpr int T = KS * KS;
+    constexpr int G8 = CC / 8;
+    constexpr int NCH = CIN / CC;
+    const int N = a.N, R = a.R;
+    const int PR = R + KS - 1;
+    const int buf_floats = PR * N * CC;
+    float *bufs[2] = {reinterpret_cast<float *>(conv_smem), reinterpret_cast<float *>(conv_smem) + buf_floats};
+    const int tiles_per_img = N / R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool loader = wave == 4;
+    const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int S = n_my * NCH;
+    const int ntiles = R * N / 32;
+
+    auto issue = [&](int s, float *buf) {
+        const int tile = blockIdx.x + (s / NCH) * gridDim.x;
+        const int b = tile / tiles_per_img;
+        const int y0 = (tile - b * tiles_per_img) * R;
+        const int c0 = (s % NCH) * CC;
+        const int n_instr = PR * N / 8;
+        const int sub = lane >> 3, slot = lane & 7;
+        for (int k = 0; k < n_instr; ++k) {
+            const int p0 = 8 * k;                   // 8 consecutive pixels of one patch row (N % 8 == 0)
+            const int pr = p0 / N, x0 = p0 - pr * N;
+            int gy = y0 - P + pr;
+            gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+            const int p = p0 + sub;
+            const int c4 = slot ^ ((p >> 1) & 7);
+            const float *g = a.in + (((size_t)b * N + gy) * N + x0 + sub) * CIN + c0 + c4 * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(buf + k * 256), 16, 0, 0);
+        }
+    };
+
+    if (loader && S > 0) {
+        issue(0, bufs[0]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    const int li = lane & 31, h = lane >> 5;
+    int py[MT], px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int tile = wave + 4 * mt;
+        if (tile >= ntiles) tile = wave & 3;
+        const int p = tile * 32 + li;
+        py[mt] = p / N;
+        px[mt] = p - py[mt] * N;
+    }
+    f32x16 acc[MT][NT];
+    const float4 *wbase = reinterpret_cast<const float4 *>(a.w) + (size_t)li * 2 + h;
+
+    for (int s = 0; s < S; ++s) {
+        if (loader) {
+            if (s + 1 < S) {
+                issue(s + 1, bufs[(s + 1) & 1]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            const float *patch = bufs[s & 1];
+            const int chunk = s % NCH;
+            if (chunk == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            }
+            const float4 *wp = wbase + (size_t)chunk * T * G8 * COUTP * 2;
+            int ky = 0, kx = 0;
+            int abase[MT], asw[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int col = px[mt] - P;
+                col = col < 0 ? col + N : col;
+                const int pl = py[mt] * N + col;
+                abase[mt] = pl * CC;
+                asw[mt] = ((pl >> 1) & 7) * 4;
+            }
+            float4 An[MT], Bn[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[(size_t)nt * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                An[mt] = *reinterpret_cast<const float4 *>(&patch[abase[mt] + ((4 * h) ^ asw[mt])]);
+            for (int tap = 0; tap < T; ++tap) {
+                const bool last_tap = tap == T - 1;
+                int nkx = kx + 1, nky = ky;
+                if (nkx == KS) { nkx = 0; ++nky; }
+                int abase_n[MT], asw_n[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    int col = px[mt] + nkx - P;
+                    col = col < 0 ? col + N : (col >= N ? col - N : col);
+                    const int pl = (py[mt] + nky) * N + col;
+                    abase_n[mt] = last_tap ? abase[mt] : pl * CC;
+                    asw_n[mt] = last_tap ? asw[mt] : ((pl >> 1) & 7) * 4;
+                }
+                const float4 *wp_n = last_tap ? wp : wp + (size_t)G8 * COUTP * 2;
+#pragma unroll
+                for (int g8 = 0; g8 < G8; ++g8) {
+                    float4 A[MT], Bf[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) A[mt] = An[mt];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) Bf[nt] = Bn[nt];
+                    if (g8 + 1 < G8) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[((size_t)(g8 + 1) * COUTP + nt * 32) * 2];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            An[mt] = *reinterpret_cast<const float4 *>(
+                                &patch[abase[mt] + ((((g8 + 1) * 8) + 4 * h) ^ asw[mt])]);
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp_n[(size_t)nt * 64];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            An[mt] = *reinterpret_cast<const float4 *>(&patch[abase_n[mt] + ((4 * h) ^ asw_n[mt])]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                    (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { abase[mt] = abase_n[mt]; asw[mt] = asw_n[mt]; }
+                wp = wp_n;
+                kx = nkx; ky = nky;
+            }
+            if (chunk == NCH - 1) {
+                // ---- epilogue of this tile: bias + ReLU + BatchNorm affine, NHWC store
+                const int tile_g = blockIdx.x + (s / NCH) * gridDim.x;
+                const int b = tile_g / tiles_per_img;
+                const int y0 = (tile_g - b * tiles_per_img) * R;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int tile = wave + 4 * mt;
+                    if (tile >= ntiles) continue;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = nt * 32 + li;
+                        const float bias = a.bias[co], sc = a.scale[co], sh = a.shift[co];
+                        float *o = a.out + ((size_t)b * N * N + (size_t)y0 * N) * COUT + co;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                            float vv = fmaxf(acc[mt][nt][r] + bias, 0.f);
+                            o[(size_t)p * COUT] = vv * sc + sh;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -263,7 +542,7 @@ __global__ void k_demean(double *S, int npix) {
 // ---- host side ---------------------------------------------------------------------------
 struct LayerHost {
     int cin, cout, ks, coutp, cc, ngroups;
-    float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
 };
 struct NetHost {
     int n_in, n_out;
@@ -280,6 +559,8 @@ struct qgx_generator {
     size_t cap_elems = 0;          // capacity in units of B*N*N pixels
     float *actA = nullptr, *actB = nullptr, *X = nullptr, *Y0 = nullptr, *Y1 = nullptr;
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
+    // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
+    int opt_cc = 16, opt_stage = 0, opt_persistent = 0;
     int prof_layer = -1;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
     size_t prof_used = 0;
@@ -290,14 +571,19 @@ namespace qgx {
 static const int KSZ[8] = {5, 5, 3, 3, 3, 3, 3, 3};
 static const int HID[7] = {128, 64, 32, 32, 32, 32, 32};
 
-static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool planar_in) {
+static int upf(float *&dst, const std::vector<float> &h) {
+    QGX_HIP(hipMalloc((void **)&dst, h.size() * sizeof(float)));
+    QGX_HIP(hipMemcpy(dst, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return QGX_OK;
+}
+
+// packed weights [k-group][coutp][8] for channel-chunk size cc (planar first layer: cc = cin)
+static int pack_weights(const LayerHost &L, int li, const qgx_cnn_weights *w, bool planar_in, int cc, float *&dst) {
     const int cin = L.cin, cout = L.cout, ks = L.ks, T = ks * ks;
-    L.coutp = ((cout + 31) / 32) * 32;
-    L.cc = planar_in ? cin : 32;
-    L.ngroups = planar_in ? (T * cin + 7) / 8 : (cin / L.cc) * T * (L.cc / 8);
-    std::vector<float> pw((size_t)L.ngroups * L.coutp * 8, 0.f);
+    const int ngroups = planar_in ? (T * cin + 7) / 8 : (cin / cc) * T * (cc / 8);
+    std::vector<float> pw((size_t)ngroups * L.coutp * 8, 0.f);
     const float *W = w->conv_w[li];
-    for (int g = 0; g < L.ngroups; ++g)
+    for (int g = 0; g < ngroups; ++g)
         for (int co = 0; co < cout; ++co)
             for (int e = 0; e < 8; ++e) {
                 int tap, c;
@@ -306,13 +592,26 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
                     if (kidx >= T * cin) continue;
                     tap = kidx / cin; c = kidx % cin;
                 } else {
-                    const int g8n = L.cc / 8;
+                    const int g8n = cc / 8;
                     const int g8 = g % g8n, tt = (g / g8n) % T, chunk = g / (g8n * T);
-                    tap = tt; c = chunk * L.cc + g8 * 8 + e;
+                    tap = tt; c = chunk * cc + g8 * 8 + e;
                 }
                 const int ky = tap / ks, kx = tap % ks;
                 pw[((size_t)g * L.coutp + co) * 8 + e] = W[(((size_t)co * cin + c) * ks + ky) * ks + kx];
             }
+    return upf(dst, pw);
+}
+
+static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool planar_in) {
+    const int cout = L.cout;
+    L.coutp = ((cout + 31) / 32) * 32;
+    int rc;
+    if (planar_in) {
+        if ((rc = pack_weights(L, li, w, true, L.cin, L.w))) return rc;
+    } else {
+        if ((rc = pack_weights(L, li, w, false, 16, L.w))) return rc;
+        if ((rc = pack_weights(L, li, w, false, 32, L.w32))) return rc;
+    }
     std::vector<float> bias(L.coutp, 0.f), sc(L.coutp, 1.f), sh(L.coutp, 0.f);
     for (int co = 0; co < cout; ++co) {
         bias[co] = w->conv_b[li][co];
@@ -324,13 +623,7 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
             sh[co] = w->bn_beta[li][co] - w->bn_mean[li][co] * alpha;
         }
     }
-    auto up = [](float *&dst, const std::vector<float> &h) -> int {
-        QGX_HIP(hipMalloc((void **)&dst, h.size() * sizeof(float)));
-        QGX_HIP(hipMemcpy(dst, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-        return QGX_OK;
-    };
-    int rc;
-    if ((rc = up(L.w, pw)) || (rc = up(L.bias, bias)) || (rc = up(L.scale, sc)) || (rc = up(L.shift, sh))) return rc;
+    if ((rc = upf(L.bias, bias)) || (rc = upf(L.scale, sc)) || (rc = upf(L.shift, sh))) return rc;
     return QGX_OK;
 }
 
@@ -356,7 +649,7 @@ static int prof_begin(qgx_generator *g, int layer, hipStream_t st, hipEvent_t &s
     return QGX_OK;
 }
 
-template <int CIN, int COUT, int KS, int CC, bool PLANAR_IN, bool FINAL>
+template <int CIN, int COUT, int KS, int CC, bool PLANAR_IN, bool FINAL, int SM = 0>
 static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                        int N, int cout_real, hipStream_t st) {
     hipEvent_t prof_stop;
@@ -365,24 +658,94 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
     QGX_REQUIRE(R > 0 && N % R == 0, "generator: unsupported grid size N=%d", N);
     const int ntiles = R * N / 32;
     ConvArgs a;
-    a.in = in; a.out = out; a.w = L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.in = in; a.out = out; a.w = (!PLANAR_IN && CC == 32) ? L.w32 : L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = cout_real;
     constexpr int STRIDE = PLANAR_IN ? CIN : CC + 4;
     const size_t lds = (size_t)(R + KS - 1) * N * STRIDE * sizeof(float);
     QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
     dim3 grid(B * (N / R)), block(256);
     if (ntiles <= 8) {
-        auto kern = k_conv<CIN, COUT, KS, CC, 2, PLANAR_IN, FINAL>;
+        auto kern = k_conv<CIN, COUT, KS, CC, 2, PLANAR_IN, FINAL, SM>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     } else {
-        auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL>;
+        auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL, SM>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     }
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
+}
+
+// rows per tile for the double-buffered kernel: the largest R with R | N, whole 32-pixel M-tiles,
+// at most 12 M-tiles and two unpadded patch buffers within the 160 KiB LDS
+static int choose_rows_v2(int N, int KS) {
+    if (N % 8) return 0;
+    int best = 0;
+    for (int R = 1; R <= N; ++R) {
+        if (N % R || (R * N) % 32) continue;
+        const int nt = R * N / 32;
+        if (nt > 12) break;
+        if (nt % 4) continue;                      // keep the four MFMA waves evenly loaded
+        if ((size_t)2 * (R + KS - 1) * N * 128 > 160 * 1024 - 256) continue;
+        best = R;
+    }
+    return best;
+}
+
+template <int CIN, int COUT, int KS>
+static int launch_conv2(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
+                        int N, hipStream_t st, bool &done) {
+    done = false;
+    const int R = choose_rows_v2(N, KS);
+    if (R == 0) return QGX_OK;                    // caller falls back to k_conv
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    const int ntiles = R * N / 32;
+    ConvArgs a;
+    a.in = in; a.out = out; a.w = L.w32; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.N = N; a.R = R; a.cout_real = COUT;
+    const size_t lds = (size_t)2 * (R + KS - 1) * N * 128;
+    const int total_tiles = B * (N / R);
+    int grid = 256;                               // one persistent workgroup per CU
+    if (grid > total_tiles) grid = total_tiles;
+    if (ntiles <= 8) {
+        auto kern = k_conv2<CIN, COUT, KS, 2>;
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(320), lds, st, a, total_tiles);
+    } else {
+        auto kern = k_conv2<CIN, COUT, KS, 3>;
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(320), lds, st, a, total_tiles);
+    }
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    done = true;
+    return QGX_OK;
+}
+
+// hidden layers: double-buffered persistent kernel when its LDS budget fits, else the one-shot kernel
+template <int CIN, int COUT, int KS>
+static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
+                       int N, hipStream_t st) {
+    if (g->opt_persistent) {
+        bool done;
+        int rc = launch_conv2<CIN, COUT, KS>(g, layer, L, in, out, B, N, st, done);
+        if (rc || done) return rc;
+    }
+#define QGX_DISPATCH_SM(CCV)                                                                               \
+    switch (g->opt_stage) {                                                                                \
+        case 1: return launch_conv<CIN, COUT, KS, CCV, false, false, 1>(g, layer, L, in, out, B, N, COUT, st); \
+        case 2: return launch_conv<CIN, COUT, KS, CCV, false, false, 2>(g, layer, L, in, out, B, N, COUT, st); \
+        case 3: return launch_conv<CIN, COUT, KS, CCV, false, false, 3>(g, layer, L, in, out, B, N, COUT, st); \
+        case 4: return launch_conv<CIN, COUT, KS, CCV, false, false, 4>(g, layer, L, in, out, B, N, COUT, st); \
+        case 5: return launch_conv<CIN, COUT, KS, CCV, false, false, 5>(g, layer, L, in, out, B, N, COUT, st); \
+        default: return launch_conv<CIN, COUT, KS, CCV, false, false, 0>(g, layer, L, in, out, B, N, COUT, st); \
+    }
+    if (g->opt_cc == 32) { QGX_DISPATCH_SM(32) }
+    QGX_DISPATCH_SM(16)
+#undef QGX_DISPATCH_SM
 }
 
 static int reserve(qgx_generator *g, int B, int N) {
@@ -408,13 +771,13 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
     if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false>(g, 0, net.L[0], x, A, B, N, 128, st);
     else rc = launch_conv<2, 128, 5, 2, true, false>(g, 0, net.L[0], x, A, B, N, 128, st);
     if (rc) return rc;
-    if ((rc = launch_conv<128, 64, 5, 32, false, false>(g, 1, net.L[1], A, Bb, B, N, 64, st))) return rc;
-    if ((rc = launch_conv<64, 32, 3, 32, false, false>(g, 2, net.L[2], Bb, A, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 3, net.L[3], A, Bb, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 4, net.L[4], Bb, A, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 5, net.L[5], A, Bb, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 32, 3, 32, false, false>(g, 6, net.L[6], Bb, A, B, N, 32, st))) return rc;
-    if ((rc = launch_conv<32, 2, 3, 32, false, true>(g, 7, net.L[7], A, y, B, N, net.n_out, st))) return rc;
+    if ((rc = conv_hidden<128, 64, 5>(g, 1, net.L[1], A, Bb, B, N, st))) return rc;
+    if ((rc = conv_hidden<64, 32, 3>(g, 2, net.L[2], Bb, A, B, N, st))) return rc;
+    if ((rc = conv_hidden<32, 32, 3>(g, 3, net.L[3], A, Bb, B, N, st))) return rc;
+    if ((rc = conv_hidden<32, 32, 3>(g, 4, net.L[4], Bb, A, B, N, st))) return rc;
+    if ((rc = conv_hidden<32, 32, 3>(g, 5, net.L[5], A, Bb, B, N, st))) return rc;
+    if ((rc = conv_hidden<32, 32, 3>(g, 6, net.L[6], Bb, A, B, N, st))) return rc;
+    if ((rc = launch_conv<32, 2, 3, 16, false, true>(g, 7, net.L[7], A, y, B, N, net.n_out, st))) return rc;
     return QGX_OK;
 }
 
@@ -487,7 +850,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
     for (int n = 0; n < 2; ++n)
         for (int li = 0; li < 8; ++li) {
             LayerHost &L = g->nets[n].L[li];
-            float *ptrs[] = {L.w, L.bias, L.scale, L.shift};
+            float *ptrs[] = {L.w, L.w32, L.bias, L.scale, L.shift};
             for (float *p : ptrs) if (p) (void)hipFree(p);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1};
@@ -529,5 +892,14 @@ extern "C" int qgx_generator_profile_read(qgx_generator *g, double *total_ms, in
     *total_ms = tot;
     *launches = (int64_t)(g->prof_used / 2);
     g->prof_used = 0;
+    return QGX_OK;
+}
+
+extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int value) {
+    QGX_REQUIRE(g && name, "qgx_generator_set_option: null argument");
+    if (!strcmp(name, "chunk")) { QGX_REQUIRE(value == 16 || value == 32, "chunk must be 16 or 32"); g->opt_cc = value; }
+    else if (!strcmp(name, "stage_batched")) g->opt_stage = value;   // 1 = batched; 2..5 = timing-only ablations
+    else if (!strcmp(name, "persistent")) g->opt_persistent = value ? 1 : 0;
+    else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;
 }

@@ -1,0 +1,180 @@
+// Time-averaged spectral diagnostics of the two-layer model, accumulated on the device.
+//
+// Restates pyqg 0.7.2 model.py::{_calc_diagnostics,_increment_diagnostics} and the diagnostic
+// definitions of model.py / qg_model.py (KEspec, Ensspec, entspec, APEflux, KEflux, APEgenspec,
+// KEfrictionspec, paramspec), which the reference consumes in
+// pyqg_generative/tools/comparison_tools.py:91,106,164-188,222-247 and plots as
+// calc_ispec(m, 0.5*ave_lev(KEspec)) (Google-Colab/online-simulations.ipynb cell 25).
+// All spectra carry pyqg's 1/M^2 normalisation.  PARITY UNPINNED (pyqg is not available here):
+// checked against oracle/qg_ref.py::_diag_functions only.
+#include "common.hpp"
+
+namespace qgx {
+int small_q_to_qh(const SpecDev &d, const double *q, double2 *qh, hipStream_t st);
+int small_qh_to_q(const SpecDev &d, const double2 *qh, double *q, hipStream_t st);
+int small_invert(const SpecDev &d, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st);
+int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st);
+int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st);
+int large_invert(qgx_model *m, hipStream_t st);
+
+struct DiagConst { double del1, del2, rdm2, Udiff, rek, invM2, H0, H1; };
+
+// xih_k = -wv2 * ph_k
+__global__ void k_diag_xih(SpecDev d, const double2 *ph, double2 *xih) {
+    const int sz = d.N * d.NK, b = blockIdx.y;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * sz; idx += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * 2 * sz + idx;
+        const double w = -d.wv2[idx % sz];
+        const double2 p = ph[o];
+        xih[o] = make_double2(w * p.x, w * p.y);
+    }
+}
+
+// real-space products: R3 = [ub*ptpc, vb*ptpc], R4 = [u1*xi1, v1*xi1], R5 = [u2*xi2, v2*xi2]
+__global__ void k_diag_products(SpecDev d, DiagConst c, const double *u, const double *v, const double *p,
+                                const double *xi, double *R3, double *R4, double *R5) {
+    const int rz = d.N * d.N, b = blockIdx.y;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rz; idx += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * 2 * rz + idx;
+        const double u1 = u[o], u2 = u[o + rz], v1 = v[o], v2 = v[o + rz];
+        const double ptpc = p[o] - p[o + rz];
+        const double ub = c.del1 * u1 + c.del2 * u2, vb = c.del1 * v1 + c.del2 * v2;
+        R3[o] = ub * ptpc; R3[o + rz] = vb * ptpc;
+        const double x1 = xi[o], x2 = xi[o + rz];
+        R4[o] = u1 * x1; R4[o + rz] = v1 * x1;
+        R5[o] = u2 * x2; R5[o + rz] = v2 * x2;
+    }
+}
+
+struct DiagAcc { double *KEspec, *Ensspec, *entspec, *APEflux, *KEflux, *APEgenspec, *KEfrictionspec, *paramspec; };
+
+__global__ void k_diag_accumulate(SpecDev d, DiagConst c, const double2 *qh, const double2 *ph, const double2 *S3,
+                                  const double2 *S4, const double2 *S5, const double2 *Sh, DiagAcc a) {
+    const int N = d.N, NK = d.NK, sz = N * NK, b = blockIdx.y;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < sz; idx += gridDim.x * blockDim.x) {
+        const int j = idx / NK, i = idx - j * NK;
+        const size_t o = (size_t)b * 2 * sz + idx, o2 = (size_t)b * sz + idx;
+        const double kx = d.kk[i], ly = d.ll[j], wv2 = d.wv2[idx];
+        const double2 q1 = qh[o], q2 = qh[o + sz], p1 = ph[o], p2 = ph[o + sz];
+        a.KEspec[o] += wv2 * (p1.x * p1.x + p1.y * p1.y) * c.invM2;
+        a.KEspec[o + sz] += wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
+        a.Ensspec[o] += (q1.x * q1.x + q1.y * q1.y) * c.invM2;
+        a.Ensspec[o + sz] += (q2.x * q2.x + q2.y * q2.y) * c.invM2;
+        const double ex = c.del1 * q1.x + c.del2 * q2.x, ey = c.del1 * q1.y + c.del2 * q2.y;
+        a.entspec[o2] += (ex * ex + ey * ey) * c.invM2;
+        // Jptpc = -(ik A + il B), (A,B) = S3
+        const double2 A3 = S3[o], B3 = S3[o + sz];
+        const double jx = (kx * A3.y + ly * B3.y), jy = -(kx * A3.x + ly * B3.x);
+        const double dpx = p1.x - p2.x, dpy = p1.y - p2.y;
+        a.APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * jx + dpy * jy) * c.invM2;
+        // Jpxi_k = ik A + il B
+        const double2 A4 = S4[o], B4 = S4[o + sz], A5 = S5[o], B5 = S5[o + sz];
+        const double j1x = -(kx * A4.y + ly * B4.y), j1y = (kx * A4.x + ly * B4.x);
+        const double j2x = -(kx * A5.y + ly * B5.y), j2y = (kx * A5.x + ly * B5.x);
+        a.KEflux[o2] += (c.del1 * (p1.x * j1x + p1.y * j1y) + c.del2 * (p2.x * j2x + p2.y * j2y)) * c.invM2;
+        // APEgenspec = U rd^-2 del1 del2 Re[ i k (del1 p1 + del2 p2) conj(p1 - p2) ]
+        const double bx = c.del1 * p1.x + c.del2 * p2.x, by = c.del1 * p1.y + c.del2 * p2.y;
+        // i k (bx + i by) = (-k by, k bx); Re[(.)*conj(dp)] = (-k by) dpx + (k bx) dpy
+        a.APEgenspec[o2] += c.Udiff * c.rdm2 * c.del1 * c.del2 * kx * (bx * dpy - by * dpx) * c.invM2;
+        a.KEfrictionspec[o2] += -c.rek * c.del2 * wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
+        if (Sh) {
+            const double2 s1 = Sh[o], s2 = Sh[o + sz];
+            // -Re[ sum_k Hk/H conj(ph_k) dqh_k ]
+            a.paramspec[o2] += -(c.H0 * (p1.x * s1.x + p1.y * s1.y) + c.H1 * (p2.x * s2.x + p2.y * s2.y)) * c.invM2;
+        }
+    }
+}
+
+__global__ void k_diag_scale_copy(const double *src, double *dst, size_t n, double s) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i] * s;
+}
+__global__ void k_diag_scale_S(const double *src, double *dst, size_t n, double w) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = w * src[i];
+}
+
+static dim3 dgrid(const SpecDev &d, int n) { return dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), d.B); }
+
+static int dalloc0(double *&p, size_t n) {
+    QGX_HIP(hipMalloc((void **)&p, n * sizeof(double)));
+    QGX_HIP(hipMemset(p, 0, n * sizeof(double)));
+    return QGX_OK;
+}
+
+int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st) {
+    const SpecDev &d = m->d;
+    const size_t nr = (size_t)d.B * 2 * d.N * d.N, ns2 = (size_t)d.B * 2 * d.N * d.NK * 2, n2d = (size_t)d.B * d.N * d.NK;
+    int rc;
+    if (!m->dg_R[0]) {
+        for (int i = 0; i < 5; ++i) if ((rc = dalloc0(m->dg_R[i], nr))) return rc;
+        for (int i = 0; i < 5; ++i) if ((rc = dalloc0(m->dg_S[i], ns2))) return rc;
+        for (int i = 0; i < 2; ++i) if ((rc = dalloc0(m->dg_acc[i], ns2 / 2))) return rc;
+        for (int i = 2; i < 8; ++i) if ((rc = dalloc0(m->dg_acc[i], n2d))) return rc;
+    }
+    double2 *qh = m->qh[m->cur_q];
+    double *p = m->dg_R[0], *xi = m->dg_R[1], *R3 = m->dg_R[2], *R4 = m->dg_R[3], *R5 = m->dg_R[4];
+    double2 *xih = (double2 *)m->dg_S[0], *S3 = (double2 *)m->dg_S[1], *S4 = (double2 *)m->dg_S[2],
+            *S5 = (double2 *)m->dg_S[3], *Sh = (double2 *)m->dg_S[4];
+    // _invert: ph, u, v of the current state
+    rc = m->small ? small_invert(d, qh, m->ph, m->u, m->v, st) : large_invert(m, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_diag_xih, dgrid(d, 2 * d.N * d.NK), dim3(256), 0, st, d, (const double2 *)m->ph, xih);
+    auto inv = [&](const double2 *h, double *r) { return m->small ? small_qh_to_q(d, h, r, st) : large_qh_to_q(m, h, r, st); };
+    auto fwd = [&](const double *r, double2 *h) { return m->small ? small_q_to_qh(d, r, h, st) : large_q_to_qh(m, r, h, st); };
+    if ((rc = inv(m->ph, p)) || (rc = inv(xih, xi))) return rc;
+    DiagConst c;
+    c.del1 = m->cfg.delta / (m->cfg.delta + 1.); c.del2 = 1. / (m->cfg.delta + 1.);
+    c.rdm2 = pow(m->cfg.rd, -2.0); c.Udiff = m->cfg.U1 - m->cfg.U2; c.rek = m->cfg.rek;
+    c.invM2 = d.invN2 * d.invN2; c.H0 = d.H[0] / d.Htot; c.H1 = d.H[1] / d.Htot;
+    hipLaunchKernelGGL(k_diag_products, dgrid(d, d.N * d.N), dim3(256), 0, st, d, c, (const double *)m->u,
+                       (const double *)m->v, (const double *)p, (const double *)xi, R3, R4, R5);
+    if ((rc = fwd(R3, S3)) || (rc = fwd(R4, S4)) || (rc = fwd(R5, S5))) return rc;
+    const double2 *Shp = nullptr;
+    if (S) {
+        hipLaunchKernelGGL(k_diag_scale_S, dim3(1024), dim3(256), 0, st, S, R3, nr, weight);
+        if ((rc = fwd(R3, Sh))) return rc;
+        Shp = Sh;
+    }
+    DiagAcc a;
+    a.KEspec = m->dg_acc[0]; a.Ensspec = m->dg_acc[1]; a.entspec = m->dg_acc[2]; a.APEflux = m->dg_acc[3];
+    a.KEflux = m->dg_acc[4]; a.APEgenspec = m->dg_acc[5]; a.KEfrictionspec = m->dg_acc[6]; a.paramspec = m->dg_acc[7];
+    hipLaunchKernelGGL(k_diag_accumulate, dgrid(d, d.N * d.NK), dim3(256), 0, st, d, c, (const double2 *)qh,
+                       (const double2 *)m->ph, (const double2 *)S3, (const double2 *)S4, (const double2 *)S5, Shp, a);
+    QGX_HIP(hipGetLastError());
+    m->dg_count += 1;
+    return QGX_OK;
+}
+
+}  // namespace qgx
+
+using namespace qgx;
+
+extern "C" int qgx_diag_config(qgx_model *m, int64_t start_step, int every) {
+    QGX_REQUIRE(m, "qgx_diag_config: null model");
+    m->dg_start = start_step;
+    m->dg_every = every;
+    return QGX_OK;
+}
+
+extern "C" int64_t qgx_diag_count(const qgx_model *m) { return m ? m->dg_count : -1; }
+
+extern "C" int qgx_diag_reset(qgx_model *m) {
+    QGX_REQUIRE(m, "qgx_diag_reset: null model");
+    m->dg_count = 0;
+    if (m->dg_acc[0]) {
+        const size_t ns = (size_t)m->B * 2 * m->N * m->NK, n2 = (size_t)m->B * m->N * m->NK;
+        for (int i = 0; i < 8; ++i) QGX_HIP(hipMemset(m->dg_acc[i], 0, (i < 2 ? ns : n2) * sizeof(double)));
+    }
+    return QGX_OK;
+}
+
+extern "C" int qgx_diag_get(qgx_model *m, int diag, double *out_dev, void *stream) {
+    QGX_REQUIRE(m && out_dev && diag >= 0 && diag < 8, "qgx_diag_get: bad argument");
+    QGX_REQUIRE(m->dg_count > 0 && m->dg_acc[0], "qgx_diag_get: no diagnostics accumulated yet");
+    const size_t n = (size_t)m->B * (diag < 2 ? 2 : 1) * m->N * m->NK;
+    hipLaunchKernelGGL(k_diag_scale_copy, dim3(1024), dim3(256), 0, (hipStream_t)stream,
+                       (const double *)m->dg_acc[diag], out_dev, n, 1.0 / (double)m->dg_count);
+    QGX_HIP(hipGetLastError());
+    return QGX_OK;
+}

@@ -243,7 +243,9 @@ extern "C" int qgx_destroy(qgx_model *m) {
     (void)hipSetDevice(m->cfg.device);
     void *ptrs[] = {m->t_filtr, m->t_wv2, m->t_a, m->t_kk, m->t_ll, m->t_tw, m->t_pos, m->q, m->u, m->v,
                     m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->zbuf,
-                    m->z, m->xi};
+                    m->z, m->xi, m->dg_R[0], m->dg_R[1], m->dg_R[2], m->dg_R[3], m->dg_R[4], m->dg_S[0], m->dg_S[1],
+                    m->dg_S[2], m->dg_S[3], m->dg_S[4], m->dg_acc[0], m->dg_acc[1], m->dg_acc[2], m->dg_acc[3],
+                    m->dg_acc[4], m->dg_acc[5], m->dg_acc[6], m->dg_acc[7]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete m;
     return QGX_OK;
@@ -392,6 +394,11 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
             S = p->forcing_dev;
             weight = p->weight;
             demean_in_kernel = p->demean;
+        }
+        // model.py::_calc_diagnostics: t >= dt, t >= tavestart, tc % taveints == 0 (before the time step)
+        if (m->dg_every > 0 && m->tc >= 1 && m->tc >= m->dg_start && m->tc % m->dg_every == 0) {
+            int drc = diag_increment(m, has_S ? S : nullptr, weight, st);
+            if (drc) return drc;
         }
         const int diag = (refresh_diag && s == nsteps - 1) ? 1 : 0;
         int rc = model_step_once(m, has_S, S, weight, demean_in_kernel, diag, st);

@@ -80,6 +80,9 @@ class Generator:
         check(lib.qgx_cnn_forward(self._h, inet, _ptr(x), _ptr(y), B, N, _stream()))
         return y
 
+    def set_option(self, name, value):
+        check(lib.qgx_generator_set_option(self._h, name.encode(), int(value)))
+
     def profile(self, layer):
         """Bracket every launch of conv layer `layer` (0..7; -1 = off) with HIP events."""
         check(lib.qgx_generator_profile(self._h, int(layer)))
@@ -175,6 +178,25 @@ class EnsembleEngine:
         check(lib.qgx_status_ke_cfl(self._h, _ptr(out), _stream()))
         out = out.cpu().numpy()
         return out[:, 0], out[:, 1]
+
+    # ---- time-averaged diagnostics --------------------------------------------------
+    def diag_config(self, start_step, every):
+        check(lib.qgx_diag_config(self._h, int(start_step), int(every)))
+
+    @property
+    def diag_count(self):
+        return int(lib.qgx_diag_count(self._h))
+
+    def diag_reset(self):
+        check(lib.qgx_diag_reset(self._h))
+
+    def diag(self, name):
+        """time mean of diagnostic `name` per member: (B,2,N,NK) for KEspec/Ensspec else (B,N,NK) (device tensor)"""
+        i = _lib.DIAGS.index(name)
+        shape = (self.B, 2, self.N, self.NK) if i < 2 else (self.B, self.N, self.NK)
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        check(lib.qgx_diag_get(self._h, i, _ptr(out), _stream()))
+        return out
 
     # ---- stepping -----------------------------------------------------------------
     def step(self, nsteps=1, generator=None, sampling='AR1', nsteps_decor=1, weight=1.0, seed=0,

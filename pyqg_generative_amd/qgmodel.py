@@ -79,7 +79,8 @@ class QGModel:
         self._init_grid()
         self.t = 0.
         self.taveints = math.ceil(self.taveint / self.dt)
-        self._snapshots_since_diag = 0
+        # pyqg averages diagnostics every taveints steps once t >= tavestart (model.py::_calc_diagnostics)
+        self._eng.diag_config(math.ceil(self.tavestart / self.dt - 1e-9), self.taveints)
         # pyqg's default initial condition is overwritten by every reference call site
         # (simulate.py:85,128 set_initial_condition); start from rest.
 
@@ -276,6 +277,26 @@ class QGModel:
                 print('Step: %i, Time: %3.2e, KE: %3.2e, CFL: %4.3f'
                       % (self.tc, self.t, float(np.mean(ke)), float(np.max(cfl))))
             assert np.all(cfl < 1.), 'CFL condition violated'
+
+    # ---- time-averaged diagnostics (pyqg Model.get_diagnostic) ------------------------------
+    diagnostic_names = tuple(_lib.DIAGS)
+
+    def get_diagnostic(self, name):
+        """Time mean of a spectral diagnostic, pyqg shape ((2,nl,nk) or (nl,nk)); a leading member axis
+        when n_members > 1.  Raises if nothing has been averaged yet (t < tavestart)."""
+        a = self._eng.diag(name).cpu().numpy()
+        return a[0] if self.n_members == 1 else a
+
+    def ensemble_mean_diagnostic(self, name, group=None):
+        """Mean over ALL members of the job (all ranks): one all-reduce of the per-rank sum
+        (reference: ds[spec].mean('run'), comparison_tools.py:167-168)."""
+        from . import parallel
+        local = self._eng.diag(name)
+        return parallel.ensemble_mean(local.sum(0), self.n_members, group).cpu().numpy()
+
+    @property
+    def diagnostics_count(self):
+        return self._eng.diag_count
 
     def _calc_derived_fields(self):
         pass    # p is derived on access; the remaining derived fields feed diagnostics not built yet

@@ -63,6 +63,13 @@ def snapshot_dataset(m):
         ds = xr.Dataset(data, coords={k: xr.DataArray(v[1], [v[0]]) for k, v in coords.items()})
     else:
         ds = xr.Dataset({k: (v[0], v[1]) for k, v in data.items()}, coords=coords)
+    # time-averaged spectral diagnostics, present once averaging has started (t >= tavestart)
+    if m.diagnostics_count > 0:
+        run = () if B == 1 else ('run',)
+        for name in m.diagnostic_names:
+            a = np.asarray(m.get_diagnostic(name), dtype='float32')
+            dd = run + (('lev', 'l', 'k') if a.ndim - len(run) == 3 else ('l', 'k'))
+            ds[name] = xr.DataArray(a, dd) if xr.__name__.endswith('xr_lite') else (dd, a)
     ds['time'].attrs['units'] = 'days'
     ds.attrs.update({'pyqg:nx': m.nx, 'pyqg:dt': m.dt, 'pyqg:rek': m.rek, 'pyqg:delta': m.delta,
                      'pyqg:beta': m.beta, 'pyqg:L': m.L, 'pyqg:rd': m.rd})
