@@ -202,6 +202,9 @@ int qgx_real_fma(const double *a_dev, const double *b_dev, double *out_dev, size
  * conv layer `layer` (0..7, -1 = off) of every net with HIP events on the launch stream;
  * _read synchronises those events, returns their summed duration and the launch count, and
  * clears the record. */
+/* sum += y, sumsq += y*y over Monte-Carlo samples (generate_mean_var, cgan_regression.py:139-146;
+ * cvae_regression.py:120-126), accumulated in float64 */
+int qgx_moments_accumulate(const float *y_dev, double *sum_dev, double *sumsq_dev, size_t n, void *stream);
 /* kernel-variant switches for in-process A/B measurement: "chunk" (16|32 input channels staged per
  * pass), "stage_batched" (0|1), "persistent" (0|1: loader-wave LDS-DMA variant). */
 int qgx_generator_set_option(qgx_generator *g, const char *name, int value);

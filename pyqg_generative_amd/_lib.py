@@ -77,6 +77,7 @@ SYMBOLS = [
     ('qgx_spec_div', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]),
     ('qgx_real_fma', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p,
                                C.c_double, C.c_void_p]),
+    ('qgx_moments_accumulate', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ('qgx_generator_set_option', C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ('qgx_generator_profile', C.c_int, [C.c_void_p, C.c_int]),
     ('qgx_generator_profile_read', C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

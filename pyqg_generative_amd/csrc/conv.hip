@@ -539,6 +539,15 @@ __global__ void k_demean(double *S, int npix) {
     for (int i = threadIdx.x; i < npix; i += blockDim.x) s[i] -= mu;
 }
 
+// running first and second moments over Monte-Carlo samples (generate_mean_var, cgan_regression.py:139-146)
+__global__ void k_moments(const float *y, double *sum, double *sumsq, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double v = (double)y[i];
+        sum[i] += v;
+        sumsq[i] += v * v;
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------
 struct LayerHost {
     int cin, cout, ks, coutp, cc, ngroups;
@@ -901,5 +910,14 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "stage_batched")) g->opt_stage = value;   // 1 = batched; 2..5 = timing-only ablations
     else if (!strcmp(name, "persistent")) g->opt_persistent = value ? 1 : 0;
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
+    return QGX_OK;
+}
+
+extern "C" int qgx_moments_accumulate(const float *y_dev, double *sum_dev, double *sumsq_dev, size_t n, void *stream) {
+    QGX_REQUIRE(y_dev && sum_dev && sumsq_dev && n > 0, "qgx_moments_accumulate: bad argument");
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_moments, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       y_dev, sum_dev, sumsq_dev, n);
+    QGX_HIP(hipGetLastError());
     return QGX_OK;
 }

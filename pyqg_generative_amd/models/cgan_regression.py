@@ -25,6 +25,42 @@ class _LatentCNN(Parameterization):
         return self.y_scale.denormalize(Y).squeeze().astype('float64')
 
 
+    def generate_mean_var(self, q, M=1000, seed=0, batch_size=64):
+        """Offline Monte-Carlo sampling (reference: generate_mean_var + predict,
+        cgan_regression.py:139-146,173-189): for PV snapshots q (T,2,N,N) draw M realisations of the
+        forcing with fresh on-device latent noise each; returns (one sample, mean, variance), float64,
+        in physical units (y_scale applied; variance with y_scale^2, unbiased as torch.var)."""
+        import ctypes as C
+        from .._lib import lib, check
+        from ..engine import _ptr, _stream
+        q = np.asarray(q, dtype='float64').reshape((-1, 2) + np.shape(q)[-2:])
+        T, _, N, _ = q.shape
+        sample = np.empty((T, 2, N, N)); mean = np.empty_like(sample); var = np.empty_like(sample)
+        ys = self.y_scale.std.reshape(1, 2, 1, 1).astype('float64')
+        for s0 in range(0, T, batch_size):
+            X = self.x_scale.normalize(q[s0:s0 + batch_size].astype('float32'))
+            b = X.shape[0]
+            x = torch.empty((b, 4, N, N), dtype=torch.float32, device='cuda')
+            x[:, :2] = torch.as_tensor(np.ascontiguousarray(X)).cuda()
+            z = torch.empty((b, 2, N, N), dtype=torch.float32, device='cuda')
+            ssum = torch.zeros((b, 2, N, N), dtype=torch.float64, device='cuda')
+            ssq = torch.zeros_like(ssum)
+            first = None
+            for m in range(M):
+                check(lib.qgx_noise_normal(_ptr(z), 0, b, 2 * N * N, int(seed), s0, m, 0.0, 1.0, _stream()))
+                x[:, 2:] = z
+                y = self._gen.cnn_forward(x)
+                if first is None:
+                    first = y.clone()
+                check(lib.qgx_moments_accumulate(_ptr(y), _ptr(ssum), _ptr(ssq), y.numel(), _stream()))
+            sm, sq = ssum.cpu().numpy(), ssq.cpu().numpy()
+            mu = sm / M
+            sample[s0:s0 + b] = first.cpu().numpy().astype('float64') * ys
+            mean[s0:s0 + b] = mu * ys
+            var[s0:s0 + b] = np.maximum(sq - M * mu * mu, 0.0) / max(M - 1, 1) * ys ** 2
+        return sample, mean, var
+
+
 class CGANRegression(_LatentCNN):
     kind = 'gan'
 

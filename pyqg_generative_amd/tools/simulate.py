@@ -154,3 +154,29 @@ def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n
         out[key] = xr.concat(out[key], 'time').assign_attrs({'pyqg_params': str(pyqg_params)})
     m.close()
     return out
+
+
+def run_forecast(pyqg_params, parameterization, q_init, n_ens, sampling_freq=86400, device=0, seed=0):
+    """Forecast mode (reference: simulate.py:254-293): n_ens members start from the SAME coarse-grained
+    initial PV and differ only in the latent noise; the reference runs them one after another and averages
+    with xarray, here they advance together.  Returns a Dataset holding q,u,v,psi of member 0 and the
+    ensemble means q_mean,u_mean,v_mean,psi_mean (time,lev,y,x)."""
+    xr = dataset_backend()
+    ds = run_simulation(pyqg_params, parameterization, q_init=q_init, sampling_freq=sampling_freq,
+                        n_members=n_ens, device=device, seed=seed)
+    out = xr.Dataset(coords={k: ds[k] for k in ('time', 'lev', 'x', 'y')}) if not xr.__name__.endswith('xr_lite') \
+        else xr.Dataset(coords={k: ds[k] for k in ('time', 'lev', 'x', 'y')})
+    for var in ('q', 'u', 'v', 'psi'):
+        a = np.asarray(ds[var].values)
+        if n_ens == 1:
+            a = a[:, None]
+        dims = ('time', 'lev', 'y', 'x')
+        first, mean = a[:, 0], a.mean(axis=1)
+        if xr.__name__.endswith('xr_lite'):
+            out[var] = xr.DataArray(first, dims)
+            out[var + '_mean'] = xr.DataArray(mean, dims)
+        else:
+            out[var] = (dims, first)
+            out[var + '_mean'] = (dims, mean)
+    out.attrs.update(ds.attrs)
+    return out
