@@ -40,8 +40,8 @@ def main():
         for l in layers:
             gen.profile(l)
             for vi, v in enumerate(variants):
-                for k in ('chunk', 'stage_batched', 'persistent'):
-                    gen.set_option(k, v.get(k, {'chunk': 16}.get(k, 0)))
+                for k in ('chunk', 'stage_batched', 'persistent', 'last_valu'):
+                    gen.set_option(k, v.get(k, {'chunk': 16, 'last_valu': 1}.get(k, 0)))
                 gen.cnn_forward(x)
                 torch.cuda.synchronize()
                 ms, n = gen.profile_read()

@@ -304,24 +304,24 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 
 // ---- persistent, double-buffered variant ------------------------------------------------------
 // Same tiling and MFMA mapping as k_conv, but (a) the workgroup is persistent and walks over its
-// tiles, (b) a fifth "loader" wave streams the NEXT (tile, channel-chunk) patch global -> LDS with
-// LDS-DMA (global_load_lds_dwordx4: no VGPR staging, its own vmcnt queue) into the second of two
-// buffers while the four MFMA waves consume the current one; one barrier per stage.
-// LDS-DMA writes 1 KiB per wave-instruction linearly (8 pixels x 32 channels), so the patch is
-// unpadded [pixel][32 floats] and bank conflicts are removed by XOR-swizzling the 16-byte slot
-// with (pixel >> 1) & 7 on the SOURCE address and again on the A-fragment read.
-template <int CIN, int COUT, int KS, int MT>
+// tiles, (b) a fifth "loader" wave stages the NEXT (tile, channel-chunk) patch global -> VGPR -> LDS
+// into the second of two buffers while the four MFMA waves consume the current one (its loads sit in
+// its own vmcnt queue, so they never delay the MFMA waves' weight loads); one barrier per stage.
+// (An LDS-DMA loader was measured slower: with a global_load_lds anywhere in the kernel hipcc drains
+// vmcnt(0) before every use of an ordinary load, which serialises the MFMA waves' weight prefetch.)
+template <int CIN, int COUT, int KS, int MT, int CC>
 __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
-    constexpr int CC = 32;
     constexpr int NT = (COUT + 31) / 32;
     constexpr int COUTP = NT * 32;
     constexpr int P = KS / 2;
     constexpr int T = KS * KS;
     constexpr int G8 = CC / 8;
+    constexpr int C4 = CC / 4;
     constexpr int NCH = CIN / CC;
+    constexpr int STRIDE = CC + 4;
     const int N = a.N, R = a.R;
     const int PR = R + KS - 1;
-    const int buf_floats = PR * N * CC;
+    const int buf_floats = PR * N * STRIDE;
     float *bufs[2] = {reinterpret_cast<float *>(conv_smem), reinterpret_cast<float *>(conv_smem) + buf_floats};
     const int tiles_per_img = N / R;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -330,30 +330,37 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
     const int S = n_my * NCH;
     const int ntiles = R * N / 32;
 
-    auto issue = [&](int s, float *buf) {
+    auto stage = [&](int s, float *buf) {
         const int tile = blockIdx.x + (s / NCH) * gridDim.x;
         const int b = tile / tiles_per_img;
         const int y0 = (tile - b * tiles_per_img) * R;
         const int c0 = (s % NCH) * CC;
-        const int n_instr = PR * N / 8;
-        const int sub = lane >> 3, slot = lane & 7;
-        for (int k = 0; k < n_instr; ++k) {
-            const int p0 = 8 * k;                   // 8 consecutive pixels of one patch row (N % 8 == 0)
-            const int pr = p0 / N, x0 = p0 - pr * N;
-            int gy = y0 - P + pr;
-            gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
-            const int p = p0 + sub;
-            const int c4 = slot ^ ((p >> 1) & 7);
-            const float *g = a.in + (((size_t)b * N + gy) * N + x0 + sub) * CIN + c0 + c4 * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                             (__attribute__((address_space(3))) void *)(buf + k * 256), 16, 0, 0);
+        const int total = PR * N * C4;
+        for (int base = 0; base < total; base += 64 * 16) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int it = base + u * 64 + lane;
+                if (it < total) {
+                    const int c4 = it % C4, pl = it / C4;
+                    const int pr = pl / N, x = pl - pr * N;
+                    int gy = y0 - P + pr;
+                    gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+                    v[u] = *reinterpret_cast<const float4 *>(&a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int it = base + u * 64 + lane;
+                if (it < total) {
+                    const int c4 = it % C4, pl = it / C4;
+                    *reinterpret_cast<float4 *>(&buf[pl * STRIDE + c4 * 4]) = v[u];
+                }
+            }
         }
     };
 
-    if (loader && S > 0) {
-        issue(0, bufs[0]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (loader && S > 0) stage(0, bufs[0]);
     __syncthreads();
 
     const int li = lane & 31, h = lane >> 5;
@@ -371,10 +378,7 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
 
     for (int s = 0; s < S; ++s) {
         if (loader) {
-            if (s + 1 < S) {
-                issue(s + 1, bufs[(s + 1) & 1]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (s + 1 < S) stage(s + 1, bufs[(s + 1) & 1]);
         } else {
             const float *patch = bufs[s & 1];
             const int chunk = s % NCH;
@@ -388,33 +392,28 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
             }
             const float4 *wp = wbase + (size_t)chunk * T * G8 * COUTP * 2;
             int ky = 0, kx = 0;
-            int abase[MT], asw[MT];
+            int aoff[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 int col = px[mt] - P;
                 col = col < 0 ? col + N : col;
-                const int pl = py[mt] * N + col;
-                abase[mt] = pl * CC;
-                asw[mt] = ((pl >> 1) & 7) * 4;
+                aoff[mt] = (py[mt] * N + col) * STRIDE + 4 * h;
             }
             float4 An[MT], Bn[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[(size_t)nt * 64];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                An[mt] = *reinterpret_cast<const float4 *>(&patch[abase[mt] + ((4 * h) ^ asw[mt])]);
+            for (int mt = 0; mt < MT; ++mt) An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt]]);
             for (int tap = 0; tap < T; ++tap) {
                 const bool last_tap = tap == T - 1;
                 int nkx = kx + 1, nky = ky;
                 if (nkx == KS) { nkx = 0; ++nky; }
-                int abase_n[MT], asw_n[MT];
+                int aoff_n[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     int col = px[mt] + nkx - P;
                     col = col < 0 ? col + N : (col >= N ? col - N : col);
-                    const int pl = (py[mt] + nky) * N + col;
-                    abase_n[mt] = last_tap ? abase[mt] : pl * CC;
-                    asw_n[mt] = last_tap ? asw[mt] : ((pl >> 1) & 7) * 4;
+                    aoff_n[mt] = last_tap ? aoff[mt] : ((py[mt] + nky) * N + col) * STRIDE + 4 * h;
                 }
                 const float4 *wp_n = last_tap ? wp : wp + (size_t)G8 * COUTP * 2;
 #pragma unroll
@@ -429,14 +428,13 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
                         for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[((size_t)(g8 + 1) * COUTP + nt * 32) * 2];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            An[mt] = *reinterpret_cast<const float4 *>(
-                                &patch[abase[mt] + ((((g8 + 1) * 8) + 4 * h) ^ asw[mt])]);
+                            An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt] + (g8 + 1) * 8]);
                     } else {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp_n[(size_t)nt * 64];
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            An[mt] = *reinterpret_cast<const float4 *>(&patch[abase_n[mt] + ((4 * h) ^ asw_n[mt])]);
+                            An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff_n[mt]]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
                                     (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
                 }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { abase[mt] = abase_n[mt]; asw[mt] = asw_n[mt]; }
+                for (int mt = 0; mt < MT; ++mt) aoff[mt] = aoff_n[mt];
                 wp = wp_n;
                 kx = nkx; ky = nky;
             }
@@ -478,6 +476,56 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
             }
         }
         __syncthreads();
+    }
+}
+
+// ---- last layer (32 -> n_out <= 2, 3x3): VALU kernel ---------------------------------------------
+// Two output channels would fill 2 of 32 MFMA columns; on the vector ALUs the 288x2 dot products per
+// pixel run at full useful rate: one thread per pixel, weights broadcast from scalar registers.
+struct LastWeights { float w[3 * 3 * 32 * 2]; };   // [tap][c][2], passed BY VALUE: kernarg -> scalar loads
+
+template <int CIN, int KS>
+__global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
+    constexpr int P = KS / 2, T = KS * KS, STRIDE = CIN + 4, C4 = CIN / 4;
+    float *patch = reinterpret_cast<float *>(conv_smem);
+    const int N = a.N, R = a.R;
+    const int tiles_per_img = N / R;
+    const int b = blockIdx.x / tiles_per_img;
+    const int y0 = (blockIdx.x - b * tiles_per_img) * R;
+    const int PR = R + KS - 1;
+    for (int it = threadIdx.x; it < PR * N * C4; it += 256) {
+        const int c4 = it % C4, pl = it / C4;
+        const int pr = pl / N, x = pl - pr * N;
+        int gy = y0 - P + pr;
+        gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+        *reinterpret_cast<float4 *>(&patch[pl * STRIDE + c4 * 4]) =
+            *reinterpret_cast<const float4 *>(&a.in[(((size_t)b * N + gy) * N + x) * CIN + c4 * 4]);
+    }
+    __syncthreads();
+    const float *w = lw.w;
+    for (int p = threadIdx.x; p < R * N; p += 256) {
+        const int py = p / N, px = p - py * N;
+        float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 1
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                int col = px + kx - P;
+                col = col < 0 ? col + N : (col >= N ? col - N : col);
+                const float *src = &patch[((py + ky) * N + col) * STRIDE];
+                const float *wt = w + (ky * KS + kx) * CIN * 2;
+#pragma unroll
+                for (int c4 = 0; c4 < C4; ++c4) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + c4 * 4);
+                    acc0 = fmaf(v.x, wt[(c4 * 4 + 0) * 2], acc0); acc1 = fmaf(v.x, wt[(c4 * 4 + 0) * 2 + 1], acc1);
+                    acc0 = fmaf(v.y, wt[(c4 * 4 + 1) * 2], acc0); acc1 = fmaf(v.y, wt[(c4 * 4 + 1) * 2 + 1], acc1);
+                    acc0 = fmaf(v.z, wt[(c4 * 4 + 2) * 2], acc0); acc1 = fmaf(v.z, wt[(c4 * 4 + 2) * 2 + 1], acc1);
+                    acc0 = fmaf(v.w, wt[(c4 * 4 + 3) * 2], acc0); acc1 = fmaf(v.w, wt[(c4 * 4 + 3) * 2 + 1], acc1);
+                }
+            }
+        float *o = a.out + (size_t)b * a.cout_real * N * N + (size_t)y0 * N + p;
+        o[0] = acc0 + a.bias[0];
+        if (a.cout_real > 1) o[(size_t)N * N] = acc1 + a.bias[1];
     }
 }
 
@@ -551,6 +599,7 @@ __global__ void k_moments(const float *y, double *sum, double *sumsq, size_t n) 
 // ---- host side ---------------------------------------------------------------------------
 struct LayerHost {
     int cin, cout, ks, coutp, cc, ngroups;
+    LastWeights wv_host;   // last layer, VALU kernel layout (kernel argument)
     float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
 };
 struct NetHost {
@@ -569,7 +618,7 @@ struct qgx_generator {
     float *actA = nullptr, *actB = nullptr, *X = nullptr, *Y0 = nullptr, *Y1 = nullptr;
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
     // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
-    int opt_cc = 16, opt_stage = 0, opt_persistent = 0;
+    int opt_cc = 16, opt_stage = 0, opt_persistent = 0, opt_last_valu = 1;
     int prof_layer = -1;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
     size_t prof_used = 0;
@@ -620,6 +669,14 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
     } else {
         if ((rc = pack_weights(L, li, w, false, 16, L.w))) return rc;
         if ((rc = pack_weights(L, li, w, false, 32, L.w32))) return rc;
+    }
+    if (li == 7) {      // [tap][c][2] for the VALU last-layer kernel
+        const int cin = L.cin, ks = L.ks;
+        memset(&L.wv_host, 0, sizeof(L.wv_host));
+        for (int co = 0; co < cout && co < 2; ++co)
+            for (int c = 0; c < cin; ++c)
+                for (int t = 0; t < ks * ks; ++t)
+                    L.wv_host.w[((size_t)t * cin + c) * 2 + co] = w->conv_w[li][((size_t)co * cin + c) * ks * ks + t];
     }
     std::vector<float> bias(L.coutp, 0.f), sc(L.coutp, 1.f), sh(L.coutp, 0.f);
     for (int co = 0; co < cout; ++co) {
@@ -688,43 +745,43 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
 }
 
 // rows per tile for the double-buffered kernel: the largest R with R | N, whole 32-pixel M-tiles,
-// at most 12 M-tiles and two unpadded patch buffers within the 160 KiB LDS
-static int choose_rows_v2(int N, int KS) {
-    if (N % 8) return 0;
+// a multiple of 4 M-tiles (at most 12) and `wgs` workgroups' double buffers within the 160 KiB LDS
+static int choose_rows_v2(int N, int KS, int cc, int wgs) {
     int best = 0;
     for (int R = 1; R <= N; ++R) {
         if (N % R || (R * N) % 32) continue;
         const int nt = R * N / 32;
         if (nt > 12) break;
         if (nt % 4) continue;                      // keep the four MFMA waves evenly loaded
-        if ((size_t)2 * (R + KS - 1) * N * 128 > 160 * 1024 - 256) continue;
+        if ((size_t)wgs * 2 * (R + KS - 1) * N * (cc + 4) * 4 > 160 * 1024 - 512) continue;
         best = R;
     }
     return best;
 }
 
-template <int CIN, int COUT, int KS>
+template <int CIN, int COUT, int KS, int CC>
 static int launch_conv2(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                         int N, hipStream_t st, bool &done) {
     done = false;
-    const int R = choose_rows_v2(N, KS);
+    const int wgs = CC == 16 ? 2 : 1;             // resident workgroups per CU
+    const int R = choose_rows_v2(N, KS, CC, wgs);
     if (R == 0) return QGX_OK;                    // caller falls back to k_conv
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
     const int ntiles = R * N / 32;
     ConvArgs a;
-    a.in = in; a.out = out; a.w = L.w32; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.in = in; a.out = out; a.w = CC == 32 ? L.w32 : L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = COUT;
-    const size_t lds = (size_t)2 * (R + KS - 1) * N * 128;
+    const size_t lds = (size_t)2 * (R + KS - 1) * N * (CC + 4) * 4;
     const int total_tiles = B * (N / R);
-    int grid = 256;                               // one persistent workgroup per CU
+    int grid = 256 * wgs;                         // persistent workgroups
     if (grid > total_tiles) grid = total_tiles;
     if (ntiles <= 8) {
-        auto kern = k_conv2<CIN, COUT, KS, 2>;
+        auto kern = k_conv2<CIN, COUT, KS, 2, CC>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(320), lds, st, a, total_tiles);
     } else {
-        auto kern = k_conv2<CIN, COUT, KS, 3>;
+        auto kern = k_conv2<CIN, COUT, KS, 3, CC>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(320), lds, st, a, total_tiles);
     }
@@ -740,7 +797,8 @@ static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const fl
                        int N, hipStream_t st) {
     if (g->opt_persistent) {
         bool done;
-        int rc = launch_conv2<CIN, COUT, KS>(g, layer, L, in, out, B, N, st, done);
+        int rc = g->opt_cc == 32 ? launch_conv2<CIN, COUT, KS, 32>(g, layer, L, in, out, B, N, st, done)
+                                 : launch_conv2<CIN, COUT, KS, 16>(g, layer, L, in, out, B, N, st, done);
         if (rc || done) return rc;
     }
 #define QGX_DISPATCH_SM(CCV)                                                                               \
@@ -755,6 +813,25 @@ static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const fl
     if (g->opt_cc == 32) { QGX_DISPATCH_SM(32) }
     QGX_DISPATCH_SM(16)
 #undef QGX_DISPATCH_SM
+}
+
+static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *in, float *out, int B, int N,
+                            int n_out, hipStream_t st) {
+    const int R = choose_rows(N);
+    QGX_REQUIRE(R > 0 && N % R == 0, "generator: unsupported grid size N=%d", N);
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, 7, st, prof_stop); if (prc) return prc; }
+    ConvArgs a;
+    a.in = in; a.out = out; a.w = nullptr; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.N = N; a.R = R; a.cout_real = n_out;
+    const size_t lds = (size_t)(R + 2) * N * 36 * sizeof(float);
+    QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
+    auto kern = k_conv_last<32, 3>;
+    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(B * (N / R)), dim3(256), lds, st, a, L.wv_host);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
 }
 
 static int reserve(qgx_generator *g, int B, int N) {
@@ -786,7 +863,9 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
     if ((rc = conv_hidden<32, 32, 3>(g, 4, net.L[4], Bb, A, B, N, st))) return rc;
     if ((rc = conv_hidden<32, 32, 3>(g, 5, net.L[5], A, Bb, B, N, st))) return rc;
     if ((rc = conv_hidden<32, 32, 3>(g, 6, net.L[6], Bb, A, B, N, st))) return rc;
-    if ((rc = launch_conv<32, 2, 3, 16, false, true>(g, 7, net.L[7], A, y, B, N, net.n_out, st))) return rc;
+    if (g->opt_last_valu) rc = launch_conv_last(g, net.L[7], A, y, B, N, net.n_out, st);
+    else rc = launch_conv<32, 2, 3, 16, false, true>(g, 7, net.L[7], A, y, B, N, net.n_out, st);
+    if (rc) return rc;
     return QGX_OK;
 }
 
@@ -909,6 +988,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     if (!strcmp(name, "chunk")) { QGX_REQUIRE(value == 16 || value == 32, "chunk must be 16 or 32"); g->opt_cc = value; }
     else if (!strcmp(name, "stage_batched")) g->opt_stage = value;   // 1 = batched; 2..5 = timing-only ablations
     else if (!strcmp(name, "persistent")) g->opt_persistent = value ? 1 : 0;
+    else if (!strcmp(name, "last_valu")) g->opt_last_valu = value ? 1 : 0;
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;
 }
