@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 import pyqg_generative_amd as qa
 from pyqg_generative_amd import weights
 
+OPTS = {'chunk': 32, 'last_valu': 1, 'first_split': 2, 'v3': -1}      # option -> default
 MAC = [12800, 204800, 18432, 9216, 9216, 9216, 9216, 576]
 
 
@@ -23,8 +24,7 @@ def main():
     ap.add_argument('--nx', type=int, default=64)
     ap.add_argument('--rounds', type=int, default=7)
     ap.add_argument('--layers', default='1,3,2,0,7')
-    ap.add_argument('--variants', default='chunk=16,stage_batched=0;chunk=16,stage_batched=1;'
-                                          'chunk=32,stage_batched=0;chunk=32,stage_batched=1;persistent=1,chunk=32')
+    ap.add_argument('--variants', default='v3=0,chunk=16;v3=0,chunk=32;v3=1;v3=2')
     args = ap.parse_args()
     B, N = args.members, args.nx
     nets, xs, ys = weights.load_npz(os.path.join(ROOT, 'tests', 'golden', 'weights_gan.npz'), 'gan')
@@ -33,15 +33,25 @@ def main():
     variants = [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in v.split(',')) for v in args.variants.split(';')]
     layers = [int(l) for l in args.layers.split(',')]
     res = {(vi, l): [] for vi in range(len(variants)) for l in layers}
+    # correctness of every variant against variant 0 (exact f32 MFMA: identical sums up to ordering)
+    outs = []
+    for v in variants:
+        for k in OPTS:
+            gen.set_option(k, v.get(k, OPTS[k]))
+        outs.append(gen.cnn_forward(x).clone())
+    torch.cuda.synchronize()
+    for v, o in zip(variants, outs):
+        print(f'  check {str(v):50s} max|diff| vs first = {(o - outs[0]).abs().max().item():.3e}  (max|y| = {outs[0].abs().max().item():.3e})')
     for _ in range(3):
         gen.cnn_forward(x)
     torch.cuda.synchronize()
     for r in range(args.rounds):
         for l in layers:
             gen.profile(l)
-            for vi, v in enumerate(variants):
-                for k in ('chunk', 'stage_batched', 'persistent', 'last_valu'):
-                    gen.set_option(k, v.get(k, {'chunk': 16, 'last_valu': 1}.get(k, 0)))
+            for vi in np.random.permutation(len(variants)):
+                v = variants[vi]
+                for k in OPTS:
+                    gen.set_option(k, v.get(k, OPTS[k]))
                 gen.cnn_forward(x)
                 torch.cuda.synchronize()
                 ms, n = gen.profile_read()

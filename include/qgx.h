@@ -205,8 +205,9 @@ int qgx_real_fma(const double *a_dev, const double *b_dev, double *out_dev, size
 /* sum += y, sumsq += y*y over Monte-Carlo samples (generate_mean_var, cgan_regression.py:139-146;
  * cvae_regression.py:120-126), accumulated in float64 */
 int qgx_moments_accumulate(const float *y_dev, double *sum_dev, double *sumsq_dev, size_t n, void *stream);
-/* kernel-variant switches for in-process A/B measurement: "chunk" (16|32 input channels staged per
- * pass), "stage_batched" (0|1), "persistent" (0|1: loader-wave LDS-DMA variant). */
+/* kernel-variant switches for in-process A/B measurement (bench_tools/ab_conv.py): "chunk" (16|32 input
+ * channels staged per pass of k_conv), "v3" (-1 auto | 0 | 1 | 2: LDS-operand kernel k_conv3),
+ * "last_valu" (0|1), "first_split" (1|2|4 output-channel slices of the first layer). */
 int qgx_generator_set_option(qgx_generator *g, const char *name, int value);
 int qgx_generator_profile(qgx_generator *g, int layer);
 int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches);

@@ -25,6 +25,7 @@
 namespace qgx {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const float *in;       // NHWC (B,N,N,CIN) or planar (B,CIN,N,N)
@@ -36,10 +37,12 @@ struct ConvArgs {
 
 extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
-template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL, int SM = 0>
+template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL, int CSPLIT = 1>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
-    constexpr int NT = (COUT + 31) / 32;
-    constexpr int COUTP = NT * 32;
+    constexpr int NTF = (COUT + 31) / 32;        // all output-channel tiles of the layer
+    constexpr int NT = NTF / CSPLIT;             // tiles owned by this workgroup (blockIdx.y picks the slice)
+    constexpr int COUTP = NTF * 32;
+    const int nt0 = CSPLIT > 1 ? blockIdx.y * NT : 0;
     constexpr int P = KS / 2;
     constexpr int T = KS * KS;
     constexpr int STRIDE = PLANAR_IN ? CIN : CC + 4;   // floats per patch pixel
@@ -73,34 +76,13 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 
     if constexpr (PLANAR_IN) {
         // ---- stage the whole (tiny) input patch: patch[(pr*N + x)*CIN + c]
-        // (loads are issued in batches of 8 before any LDS store so that their latencies overlap)
-        {
-            const int total = PR * CIN * N;
-            for (int base = 0; base < total; base += 256 * 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int it = base + u * 256 + threadIdx.x;
-                    if (it < total) {
-                        const int x = it % N;
-                        const int c = (it / N) % CIN;
-                        const int pr = it / (N * CIN);
-                        int gy = y0 - P + pr;
-                        gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
-                        v[u] = a.in[(((size_t)b * CIN + c) * N + gy) * N + x];
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int it = base + u * 256 + threadIdx.x;
-                    if (it < total) {
-                        const int x = it % N;
-                        const int c = (it / N) % CIN;
-                        const int pr = it / (N * CIN);
-                        patch[(pr * N + x) * CIN + c] = v[u];
-                    }
-                }
-            }
+        for (int it = threadIdx.x; it < PR * CIN * N; it += 256) {
+            const int x = it % N;
+            const int c = (it / N) % CIN;
+            const int pr = it / (N * CIN);
+            int gy = y0 - P + pr;
+            gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+            patch[(pr * N + x) * CIN + c] = a.in[(((size_t)b * CIN + c) * N + gy) * N + x];
         }
         __syncthreads();
         constexpr int NG = (T * CIN + 7) / 8;
@@ -108,7 +90,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         for (int g = 0; g < NG; ++g) {
             float4 A[MT], Bf[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Bf[nt] = wp[((size_t)g * COUTP + nt * 32) * 2];
+            for (int nt = 0; nt < NT; ++nt) Bf[nt] = wp[((size_t)g * COUTP + (nt0 + nt) * 32) * 2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (CIN == 4) {
@@ -148,51 +130,16 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         for (int c0 = 0; c0 < CIN; c0 += CC) {
             __syncthreads();
             // ---- stage patch chunk: (PR rows) x N x CC channels, pixel stride CC+4 floats
-            if constexpr (SM == 2) {
-                // ablation: no staging traffic
-            } else if constexpr (SM == 0 || SM >= 3) {
-                for (int it = threadIdx.x; it < PR * N * C4; it += 256) {
-                    const int c4 = it % C4;
-                    const int x = (it / C4) % N;
-                    const int pr = it / (C4 * N);
-                    int gy = y0 - P + pr;
-                    gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
-                    const float4 vv = *reinterpret_cast<const float4 *>(
-                        &a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
-                    *reinterpret_cast<float4 *>(&patch[(pr * N + x) * STRIDE + c4 * 4]) = vv;
-                }
-            } else {
-            // All loads of a batch are in flight before the first LDS store (a load->store pair per
-            // iteration would serialise 8-16 HBM/L2 latencies per stage).
-            {
-                const int total = PR * N * C4;
-                for (int base = 0; base < total; base += 256 * 8) {
-                    float4 v[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int it = base + u * 256 + threadIdx.x;
-                        if (it < total) {
-                            const int c4 = it % C4;
-                            const int pl = it / C4;
-                            const int pr = pl / N, x = pl - pr * N;
-                            int gy = y0 - P + pr;
-                            gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
-                            v[u] = *reinterpret_cast<const float4 *>(
-                                &a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int it = base + u * 256 + threadIdx.x;
-                        if (it < total) {
-                            const int c4 = it % C4;
-                            const int pl = it / C4;
-                            *reinterpret_cast<float4 *>(&patch[pl * STRIDE + c4 * 4]) = v[u];
-                        }
-                    }
-                }
+            for (int it = threadIdx.x; it < PR * N * C4; it += 256) {
+                const int c4 = it % C4;
+                const int x = (it / C4) % N;
+                const int pr = it / (C4 * N);
+                int gy = y0 - P + pr;
+                gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
+                const float4 vv = *reinterpret_cast<const float4 *>(
+                    &a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
+                *reinterpret_cast<float4 *>(&patch[(pr * N + x) * STRIDE + c4 * 4]) = vv;
             }
-                        }
             __syncthreads();
             // ---- K loop over (tap, 8-channel group), software pipelined: the A fragment (LDS) and the
             // B fragment (packed weights, L2) of step i+1 are requested before the MFMAs of step i.
@@ -206,7 +153,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
             }
             float4 An[MT], Bn[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[(size_t)nt * 64];
+            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[(size_t)(nt0 + nt) * 64];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt]]);
             for (int tap = 0; tap < T; ++tap) {
@@ -229,25 +176,17 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) Bf[nt] = Bn[nt];
                     if (g8 + 1 < G8) {
-                        if constexpr (SM != 3 && SM != 5) {
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[((size_t)(g8 + 1) * COUTP + nt * 32) * 2];
-                        }
-                        if constexpr (SM != 4 && SM != 5) {
+                        for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[((size_t)(g8 + 1) * COUTP + (nt0 + nt) * 32) * 2];
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt] + (g8 + 1) * 8]);
-                        }
+                        for (int mt = 0; mt < MT; ++mt)
+                            An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt] + (g8 + 1) * 8]);
                     } else {
-                        if constexpr (SM != 3 && SM != 5) {
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp_n[(size_t)nt * 64];
-                        }
-                        if constexpr (SM != 4 && SM != 5) {
+                        for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp_n[(size_t)(nt0 + nt) * 64];
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff_n[mt]]);
-                        }
+                        for (int mt = 0; mt < MT; ++mt)
+                            An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff_n[mt]]);
                     }
                     // keep the prefetch ABOVE this step's MFMAs (hipcc otherwise sinks the loads to their use)
                     __builtin_amdgcn_sched_barrier(0);
@@ -276,7 +215,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         if (tile >= ntiles) continue;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int co = nt * 32 + li;
+            const int co = (nt0 + nt) * 32 + li;
             const float bias = a.bias[co];
             if constexpr (FINAL) {
                 if (co < a.cout_real) {
@@ -302,15 +241,15 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     }
 }
 
-// ---- persistent, double-buffered variant ------------------------------------------------------
-// Same tiling and MFMA mapping as k_conv, but (a) the workgroup is persistent and walks over its
-// tiles, (b) a fifth "loader" wave stages the NEXT (tile, channel-chunk) patch global -> VGPR -> LDS
-// into the second of two buffers while the four MFMA waves consume the current one (its loads sit in
-// its own vmcnt queue, so they never delay the MFMA waves' weight loads); one barrier per stage.
-// (An LDS-DMA loader was measured slower: with a global_load_lds anywhere in the kernel hipcc drains
-// vmcnt(0) before every use of an ordinary load, which serialises the MFMA waves' weight prefetch.)
-template <int CIN, int COUT, int KS, int MT, int CC>
-__global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
+// ---- hidden layers, LDS-only operands with register-prefetched staging ---------------------------
+// Both MFMA operands come from LDS: the input patch (double buffered per 16-channel chunk) and the
+// weight slice of TPS taps (double buffered).  The global loads that fetch the NEXT weight slice and
+// the next chunk's patch are issued at the start of a stage into registers and written to the idle
+// LDS buffers at its end, so the K loop contains no vector-memory instruction and nothing ever waits
+// on HBM/L2 latency except the stage boundary.  The workgroup is persistent over its tiles, so the
+// prefetch also runs across tile boundaries; one barrier per stage.
+template <int CIN, int COUT, int KS, int CC, int MT, int TPS, int PPT>
+__global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
     constexpr int NT = (COUT + 31) / 32;
     constexpr int COUTP = NT * 32;
     constexpr int P = KS / 2;
@@ -319,70 +258,100 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
     constexpr int C4 = CC / 4;
     constexpr int NCH = CIN / CC;
     constexpr int STRIDE = CC + 4;
+    constexpr int NSL = T / TPS;                        // weight slices per chunk
+    constexpr int WSL = TPS * G8 * 2 * COUTP * 4;       // floats per slice, layout [tap][g8][h][cout][4]
+    constexpr int WF4 = WSL / 4;
+    constexpr int WPT = (WF4 + 255) / 256;
+    static_assert(T % TPS == 0, "taps per slice must divide the tap count");
     const int N = a.N, R = a.R;
     const int PR = R + KS - 1;
-    const int buf_floats = PR * N * STRIDE;
-    float *bufs[2] = {reinterpret_cast<float *>(conv_smem), reinterpret_cast<float *>(conv_smem) + buf_floats};
+    const int patch_floats = PR * N * STRIDE;
+    // LDS addresses are always formed arithmetically from the shared symbol: selecting between pointers
+    // kept in an array makes hipcc lose the address space and emit flat_load (vmcnt+lgkmcnt, full drains)
+    float *const lds0 = reinterpret_cast<float *>(conv_smem);
+    float *const wlds0 = lds0 + 2 * patch_floats;
     const int tiles_per_img = N / R;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool loader = wave == 4;
+    const int li = lane & 31, h = lane >> 5;
     const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int S = n_my * NCH;
     const int ntiles = R * N / 32;
+    const int PF4 = PR * N * C4;                        // float4 per patch chunk
+    const int PSH = (PF4 + NSL - 1) / NSL;              // patch float4 fetched per stage
 
-    auto stage = [&](int s, float *buf) {
-        const int tile = blockIdx.x + (s / NCH) * gridDim.x;
-        const int b = tile / tiles_per_img;
-        const int y0 = (tile - b * tiles_per_img) * R;
-        const int c0 = (s % NCH) * CC;
-        const int total = PR * N * C4;
-        for (int base = 0; base < total; base += 64 * 16) {
-            float4 v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int it = base + u * 64 + lane;
-                if (it < total) {
-                    const int c4 = it % C4, pl = it / C4;
-                    const int pr = pl / N, x = pl - pr * N;
-                    int gy = y0 - P + pr;
-                    gy = gy < 0 ? gy + N : (gy >= N ? gy - N : gy);
-                    v[u] = *reinterpret_cast<const float4 *>(&a.in[(((size_t)b * N + gy) * N + x) * CIN + c0 + c4 * 4]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int it = base + u * 64 + lane;
-                if (it < total) {
-                    const int c4 = it % C4, pl = it / C4;
-                    *reinterpret_cast<float4 *>(&buf[pl * STRIDE + c4 * 4]) = v[u];
-                }
-            }
+    // The staging code below is written inline (no helper lambdas taking array references): hipcc
+    // keeps the prefetch registers in VGPRs only when every index is a compile-time constant in the
+    // kernel body; through a by-reference helper they went to scratch and each load was drained.
+#define QGX_PATCH_LOAD(TI, CH, LO, HI, V)                                                                   \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            int it_ = (LO) + u * 256 + threadIdx.x;                                                         \
+            it_ = it_ < (HI) ? it_ : (HI) - 1; /* clamped: branch-free, the store is predicated instead */  \
+            const int c4_ = it_ % C4, pl_ = it_ / C4;                                                       \
+            const int pr_ = pl_ / N, x_ = pl_ - pr_ * N;                                                    \
+            int gy_ = y0_ - P + pr_;                                                                        \
+            gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                           \
+            V[u] = *reinterpret_cast<const f32x4 *>(                                                        \
+                &a.in[(((size_t)b_ * N + gy_) * N + x_) * CIN + (CH) * CC + c4_ * 4]);                      \
+        }                                                                                                   \
+    }
+#define QGX_PATCH_STORE(BUF, LO, HI, V)                                                                     \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            const int it_ = (LO) + u * 256 + threadIdx.x;                                                   \
+            if (it_ < (HI)) {                                                                               \
+                const int c4_ = it_ % C4, pl_ = it_ / C4;                                                   \
+                *reinterpret_cast<f32x4 *>(&(BUF)[pl_ * STRIDE + c4_ * 4]) = V[u];                          \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+#define QGX_W_LOAD(CH, SL, V)                                                                               \
+    {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(a.w) + ((size_t)(CH) * NSL + (SL)) * WF4;       \
+        _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
+            const int it_ = u * 256 + threadIdx.x;                                                          \
+            V[u] = src_[it_ < WF4 ? it_ : WF4 - 1];                                                         \
+        }                                                                                                   \
+    }
+#define QGX_W_STORE(BUF, V)                                                                                 \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
+            const int it_ = u * 256 + threadIdx.x;                                                          \
+            if (it_ < WF4) reinterpret_cast<f32x4 *>(BUF)[it_] = V[u];                                      \
+        }                                                                                                   \
+    }
+
+    if (n_my == 0) return;
+    // ---- prologue: first chunk's patch and first weight slice, synchronously
+    {
+        f32x4 pv[PPT];
+        for (int lo = 0; lo < PF4; lo += PPT * 256) {
+            const int hi = lo + PPT * 256 < PF4 ? lo + PPT * 256 : PF4;
+            QGX_PATCH_LOAD(0, 0, lo, hi, pv)
+            QGX_PATCH_STORE(lds0, lo, hi, pv)
         }
-    };
-
-    if (loader && S > 0) stage(0, bufs[0]);
+        f32x4 wv[WPT];
+        QGX_W_LOAD(0, 0, wv)
+        QGX_W_STORE(wlds0, wv)
+    }
     __syncthreads();
 
-    const int li = lane & 31, h = lane >> 5;
     int py[MT], px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int tile = wave + 4 * mt;
-        if (tile >= ntiles) tile = wave & 3;
+        if (tile >= ntiles) tile = wave;
         const int p = tile * 32 + li;
         py[mt] = p / N;
         px[mt] = p - py[mt] * N;
     }
     f32x16 acc[MT][NT];
-    const float4 *wbase = reinterpret_cast<const float4 *>(a.w) + (size_t)li * 2 + h;
-
-    for (int s = 0; s < S; ++s) {
-        if (loader) {
-            if (s + 1 < S) stage(s + 1, bufs[(s + 1) & 1]);
-        } else {
-            const float *patch = bufs[s & 1];
-            const int chunk = s % NCH;
-            if (chunk == 0) {
+    int cur_p = 0, cur_w = 0;
+    for (int ti = 0; ti < n_my; ++ti) {
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch == 0) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -390,94 +359,127 @@ __global__ __launch_bounds__(320) void k_conv2(ConvArgs a, int total_tiles) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
             }
-            const float4 *wp = wbase + (size_t)chunk * T * G8 * COUTP * 2;
-            int ky = 0, kx = 0;
-            int aoff[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                int col = px[mt] - P;
-                col = col < 0 ? col + N : col;
-                aoff[mt] = (py[mt] * N + col) * STRIDE + 4 * h;
-            }
-            float4 An[MT], Bn[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[(size_t)nt * 64];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt]]);
-            for (int tap = 0; tap < T; ++tap) {
-                const bool last_tap = tap == T - 1;
-                int nkx = kx + 1, nky = ky;
-                if (nkx == KS) { nkx = 0; ++nky; }
-                int aoff_n[MT];
+            // the chunk after this one (possibly the first chunk of the next tile)
+            const int nch = ch + 1 < NCH ? ch + 1 : 0;
+            const int nti = ch + 1 < NCH ? ti : ti + 1;
+            const bool have_next_chunk = nti < n_my;
+            for (int sl = 0; sl < NSL; ++sl) {
+                // ---- prefetch into registers (consumed after the K loop of this stage)
+                f32x4 wv[WPT], pv[PPT];
+                const bool last_stage = !have_next_chunk && sl == NSL - 1;
+                // (always issued, from a valid dummy source on the very last stage: no branch around loads)
+                {
+                    const int wch = sl + 1 < NSL ? ch : (have_next_chunk ? nch : ch);
+                    const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
+                    QGX_W_LOAD(wch, wsl, wv)
+                }
+                const int plo = sl * PSH, phi = (sl + 1) * PSH < PF4 ? (sl + 1) * PSH : PF4;
+                QGX_PATCH_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch, plo, phi, pv)
+
+                // ---- K loop over the TPS taps of this slice; operands from LDS, pipelined one step ahead
+                const float *patch = lds0 + cur_p * patch_floats;
+                const float *wl = wlds0 + cur_w * WSL + h * COUTP * 4 + li * 4;
+                const int tap0 = sl * TPS;
+                int ky = tap0 / KS, kx = tap0 - ky * KS;
+                int aoff[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    int col = px[mt] + nkx - P;
+                    int col = px[mt] + kx - P;
                     col = col < 0 ? col + N : (col >= N ? col - N : col);
-                    aoff_n[mt] = last_tap ? aoff[mt] : ((py[mt] + nky) * N + col) * STRIDE + 4 * h;
+                    aoff[mt] = ((py[mt] + ky) * N + col) * STRIDE + 4 * h;
                 }
-                const float4 *wp_n = last_tap ? wp : wp + (size_t)G8 * COUTP * 2;
+                float4 An[MT], Bn[NT];
 #pragma unroll
-                for (int g8 = 0; g8 < G8; ++g8) {
-                    float4 A[MT], Bf[NT];
+                for (int nt = 0; nt < NT; ++nt) Bn[nt] = *reinterpret_cast<const float4 *>(wl + nt * 128);
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) A[mt] = An[mt];
+                for (int mt = 0; mt < MT; ++mt) An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt]]);
+                for (int tl = 0; tl < TPS; ++tl) {
+                    const bool last_tap = tl == TPS - 1;
+                    int nkx = kx + 1, nky = ky;
+                    if (nkx == KS) { nkx = 0; ++nky; }
+                    int aoff_n[MT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) Bf[nt] = Bn[nt];
-                    if (g8 + 1 < G8) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp[((size_t)(g8 + 1) * COUTP + nt * 32) * 2];
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt] + (g8 + 1) * 8]);
-                    } else {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) Bn[nt] = wp_n[(size_t)nt * 64];
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff_n[mt]]);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        int col = px[mt] + nkx - P;
+                        col = col < 0 ? col + N : (col >= N ? col - N : col);
+                        aoff_n[mt] = last_tap ? aoff[mt] : ((py[mt] + nky) * N + col) * STRIDE + 4 * h;
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    const float *wl_t = wl + (size_t)tl * G8 * 2 * COUTP * 4;
+                    const float *wl_n = last_tap ? wl_t : wl_t + (size_t)G8 * 2 * COUTP * 4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int g8 = 0; g8 < G8; ++g8) {
+                        float4 A[MT], Bf[NT];
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
+                        for (int mt = 0; mt < MT; ++mt) A[mt] = An[mt];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) Bf[nt] = Bn[nt];
+                        if (g8 + 1 < G8) {
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                                    (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
+                                Bn[nt] = *reinterpret_cast<const float4 *>(wl_t + (size_t)(g8 + 1) * 2 * COUTP * 4 + nt * 128);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff[mt] + (g8 + 1) * 8]);
+                        } else {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) Bn[nt] = *reinterpret_cast<const float4 *>(wl_n + nt * 128);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                An[mt] = *reinterpret_cast<const float4 *>(&patch[aoff_n[mt]]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                        (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) aoff[mt] = aoff_n[mt];
+                    kx = nkx; ky = nky;
                 }
+
+                // ---- retire the prefetch into the idle LDS buffers
+                if (!last_stage) QGX_W_STORE(wlds0 + (cur_w ^ 1) * WSL, wv)
+                if (have_next_chunk) QGX_PATCH_STORE(lds0 + (cur_p ^ 1) * patch_floats, plo, phi, pv)
+
+                if (sl == NSL - 1 && ch == NCH - 1) {
+                    // ---- epilogue of this tile: bias + ReLU + BatchNorm affine, NHWC store
+                    const int tile_g = blockIdx.x + ti * gridDim.x;
+                    const int b = tile_g / tiles_per_img;
+                    const int y0 = (tile_g - b * tiles_per_img) * R;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) aoff[mt] = aoff_n[mt];
-                wp = wp_n;
-                kx = nkx; ky = nky;
-            }
-            if (chunk == NCH - 1) {
-                // ---- epilogue of this tile: bias + ReLU + BatchNorm affine, NHWC store
-                const int tile_g = blockIdx.x + (s / NCH) * gridDim.x;
-                const int b = tile_g / tiles_per_img;
-                const int y0 = (tile_g - b * tiles_per_img) * R;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int tile = wave + 4 * mt;
+                        if (tile >= ntiles) continue;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int tile = wave + 4 * mt;
-                    if (tile >= ntiles) continue;
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int co = nt * 32 + li;
+                            const float bias = a.bias[co], sc = a.scale[co], sh = a.shift[co];
+                            float *o = a.out + ((size_t)b * N * N + (size_t)y0 * N) * COUT + co;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int co = nt * 32 + li;
-                        const float bias = a.bias[co], sc = a.scale[co], sh = a.shift[co];
-                        float *o = a.out + ((size_t)b * N * N + (size_t)y0 * N) * COUT + co;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                            float vv = fmaxf(acc[mt][nt][r] + bias, 0.f);
-                            o[(size_t)p * COUT] = vv * sc + sh;
+                            for (int r = 0; r < 16; ++r) {
+                                const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                float vv = fmaxf(acc[mt][nt][r] + bias, 0.f);
+                                o[(size_t)p * COUT] = vv * sc + sh;
+                            }
                         }
                     }
                 }
+                __syncthreads();
+                cur_w ^= 1;
             }
+            cur_p ^= 1;
         }
-        __syncthreads();
     }
 }
+#undef QGX_PATCH_LOAD
+#undef QGX_PATCH_STORE
+#undef QGX_W_LOAD
+#undef QGX_W_STORE
 
 // ---- last layer (32 -> n_out <= 2, 3x3): VALU kernel ---------------------------------------------
 // Two output channels would fill 2 of 32 MFMA columns; on the vector ALUs the 288x2 dot products per
@@ -600,6 +602,7 @@ __global__ void k_moments(const float *y, double *sum, double *sumsq, size_t n) 
 struct LayerHost {
     int cin, cout, ks, coutp, cc, ngroups;
     LastWeights wv_host;   // last layer, VALU kernel layout (kernel argument)
+    float *wl16 = nullptr;   // k_conv3 layout [chunk][tap][g8][h][coutp][4], 16-channel chunks
     float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
 };
 struct NetHost {
@@ -618,7 +621,7 @@ struct qgx_generator {
     float *actA = nullptr, *actB = nullptr, *X = nullptr, *Y0 = nullptr, *Y1 = nullptr;
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
     // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
-    int opt_cc = 16, opt_stage = 0, opt_persistent = 0, opt_last_valu = 1;
+    int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1;
     int prof_layer = -1;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
     size_t prof_used = 0;
@@ -669,6 +672,21 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
     } else {
         if ((rc = pack_weights(L, li, w, false, 16, L.w))) return rc;
         if ((rc = pack_weights(L, li, w, false, 32, L.w32))) return rc;
+        {   // LDS-operand layout for k_conv3
+            const int cin = L.cin, ks = L.ks, T = ks * ks, cc = 16, g8n = cc / 8, nch = cin / cc;
+            std::vector<float> pw((size_t)nch * T * g8n * 2 * L.coutp * 4, 0.f);
+            for (int ch = 0; ch < nch; ++ch)
+                for (int t = 0; t < T; ++t)
+                    for (int g8 = 0; g8 < g8n; ++g8)
+                        for (int hh = 0; hh < 2; ++hh)
+                            for (int co = 0; co < cout; ++co)
+                                for (int e = 0; e < 4; ++e) {
+                                    const int c = ch * cc + g8 * 8 + hh * 4 + e;
+                                    pw[(((((size_t)ch * T + t) * g8n + g8) * 2 + hh) * L.coutp + co) * 4 + e] =
+                                        w->conv_w[li][((size_t)co * cin + c) * T + t];
+                                }
+            if ((rc = upf(L.wl16, pw))) return rc;
+        }
     }
     if (li == 7) {      // [tap][c][2] for the VALU last-layer kernel
         const int cin = L.cin, ks = L.ks;
@@ -715,7 +733,7 @@ static int prof_begin(qgx_generator *g, int layer, hipStream_t st, hipEvent_t &s
     return QGX_OK;
 }
 
-template <int CIN, int COUT, int KS, int CC, bool PLANAR_IN, bool FINAL, int SM = 0>
+template <int CIN, int COUT, int KS, int CC, bool PLANAR_IN, bool FINAL, int CSPLIT = 1>
 static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                        int N, int cout_real, hipStream_t st) {
     hipEvent_t prof_stop;
@@ -729,13 +747,13 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
     constexpr int STRIDE = PLANAR_IN ? CIN : CC + 4;
     const size_t lds = (size_t)(R + KS - 1) * N * STRIDE * sizeof(float);
     QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
-    dim3 grid(B * (N / R)), block(256);
+    dim3 grid(B * (N / R), CSPLIT), block(256);
     if (ntiles <= 8) {
-        auto kern = k_conv<CIN, COUT, KS, CC, 2, PLANAR_IN, FINAL, SM>;
+        auto kern = k_conv<CIN, COUT, KS, CC, 2, PLANAR_IN, FINAL, CSPLIT>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     } else {
-        auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL, SM>;
+        auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL, CSPLIT>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     }
@@ -744,75 +762,64 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
     return QGX_OK;
 }
 
-// rows per tile for the double-buffered kernel: the largest R with R | N, whole 32-pixel M-tiles,
-// a multiple of 4 M-tiles (at most 12) and `wgs` workgroups' double buffers within the 160 KiB LDS
-static int choose_rows_v2(int N, int KS, int cc, int wgs) {
-    int best = 0;
-    for (int R = 1; R <= N; ++R) {
-        if (N % R || (R * N) % 32) continue;
-        const int nt = R * N / 32;
-        if (nt > 12) break;
-        if (nt % 4) continue;                      // keep the four MFMA waves evenly loaded
-        if ((size_t)wgs * 2 * (R + KS - 1) * N * (cc + 4) * 4 > 160 * 1024 - 512) continue;
-        best = R;
-    }
-    return best;
-}
-
-template <int CIN, int COUT, int KS, int CC>
-static int launch_conv2(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
+// ---- k_conv3 launcher -------------------------------------------------------------------------
+template <int CIN, int COUT, int KS, int TPS>
+static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                         int N, hipStream_t st, bool &done) {
     done = false;
-    const int wgs = CC == 16 ? 2 : 1;             // resident workgroups per CU
-    const int R = choose_rows_v2(N, KS, CC, wgs);
-    if (R == 0) return QGX_OK;                    // caller falls back to k_conv
+    constexpr int CC = 16, T = KS * KS, NSL = T / TPS, NTc = (COUT + 31) / 32;
+    constexpr size_t WSLB = (size_t)TPS * (CC / 8) * 2 * NTc * 32 * 4 * sizeof(float);
+    // rows per tile: as k_conv (8 or 12 M-tiles), LDS = 2 patches + 2 weight slices
+    const int R = choose_rows(N);
+    if (R == 0 || N % R) return QGX_OK;
+    const int ntiles = R * N / 32;
+    const int PR = R + KS - 1;
+    const size_t lds = (size_t)2 * PR * N * (CC + 4) * sizeof(float) + 2 * WSLB;
+    if (lds > 160 * 1024 - 256) return QGX_OK;
+    const int PF4 = PR * N * (CC / 4);
+    const int ppt = (((PF4 + NSL - 1) / NSL) + 255) / 256;
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
-    const int ntiles = R * N / 32;
     ConvArgs a;
-    a.in = in; a.out = out; a.w = CC == 32 ? L.w32 : L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.in = in; a.out = out; a.w = L.wl16; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = COUT;
-    const size_t lds = (size_t)2 * (R + KS - 1) * N * (CC + 4) * 4;
     const int total_tiles = B * (N / R);
-    int grid = 256 * wgs;                         // persistent workgroups
+    const int wgs = lds * 2 <= 160 * 1024 ? 2 : 1;
+    int grid = 256 * wgs;
     if (grid > total_tiles) grid = total_tiles;
-    if (ntiles <= 8) {
-        auto kern = k_conv2<CIN, COUT, KS, 2, CC>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(320), lds, st, a, total_tiles);
-    } else {
-        auto kern = k_conv2<CIN, COUT, KS, 3, CC>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(320), lds, st, a, total_tiles);
+#define QGX_L3(MTV, PPTV)                                                                                     \
+    {                                                                                                         \
+        auto kern = k_conv3<CIN, COUT, KS, CC, MTV, TPS, PPTV>;                                               \
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);                             \
     }
+    const int mtv = ntiles <= 8 ? 2 : 3;
+    if (ppt <= 2) { if (mtv == 2) QGX_L3(2, 2) else QGX_L3(3, 2) }
+    else if (ppt <= 4) { if (mtv == 2) QGX_L3(2, 4) else QGX_L3(3, 4) }
+    else if (ppt <= 8) { if (mtv == 2) QGX_L3(2, 8) else QGX_L3(3, 8) }
+    else return QGX_OK;
+#undef QGX_L3
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     done = true;
     return QGX_OK;
 }
 
-// hidden layers: double-buffered persistent kernel when its LDS budget fits, else the one-shot kernel
+// hidden layers: k_conv3 (LDS-only operands, prefetched staging) where it measured faster (CIN <= 64 at
+// 64x64: -8..-10 %; the 128->64 5x5 layer ties), else the one-shot k_conv.  "v3" option: -1 auto, 0 off,
+// 1 = weight slice per tap row, 2 = per chunk.
 template <int CIN, int COUT, int KS>
 static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                        int N, hipStream_t st) {
-    if (g->opt_persistent) {
+    const int v3 = g->opt_v3 >= 0 ? g->opt_v3 : (CIN <= 64 ? 1 : 0);
+    if (v3) {
         bool done;
-        int rc = g->opt_cc == 32 ? launch_conv2<CIN, COUT, KS, 32>(g, layer, L, in, out, B, N, st, done)
-                                 : launch_conv2<CIN, COUT, KS, 16>(g, layer, L, in, out, B, N, st, done);
+        int rc = v3 == 2 ? launch_conv3<CIN, COUT, KS, KS * KS>(g, layer, L, in, out, B, N, st, done)
+                         : launch_conv3<CIN, COUT, KS, KS>(g, layer, L, in, out, B, N, st, done);
         if (rc || done) return rc;
     }
-#define QGX_DISPATCH_SM(CCV)                                                                               \
-    switch (g->opt_stage) {                                                                                \
-        case 1: return launch_conv<CIN, COUT, KS, CCV, false, false, 1>(g, layer, L, in, out, B, N, COUT, st); \
-        case 2: return launch_conv<CIN, COUT, KS, CCV, false, false, 2>(g, layer, L, in, out, B, N, COUT, st); \
-        case 3: return launch_conv<CIN, COUT, KS, CCV, false, false, 3>(g, layer, L, in, out, B, N, COUT, st); \
-        case 4: return launch_conv<CIN, COUT, KS, CCV, false, false, 4>(g, layer, L, in, out, B, N, COUT, st); \
-        case 5: return launch_conv<CIN, COUT, KS, CCV, false, false, 5>(g, layer, L, in, out, B, N, COUT, st); \
-        default: return launch_conv<CIN, COUT, KS, CCV, false, false, 0>(g, layer, L, in, out, B, N, COUT, st); \
-    }
-    if (g->opt_cc == 32) { QGX_DISPATCH_SM(32) }
-    QGX_DISPATCH_SM(16)
-#undef QGX_DISPATCH_SM
+    if (g->opt_cc == 32) return launch_conv<CIN, COUT, KS, 32, false, false>(g, layer, L, in, out, B, N, COUT, st);
+    return launch_conv<CIN, COUT, KS, 16, false, false>(g, layer, L, in, out, B, N, COUT, st);
 }
 
 static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *in, float *out, int B, int N,
@@ -854,8 +861,12 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
                        hipStream_t st) {
     int rc;
     float *A = g->actA, *Bb = g->actB;
-    if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false>(g, 0, net.L[0], x, A, B, N, 128, st);
-    else rc = launch_conv<2, 128, 5, 2, true, false>(g, 0, net.L[0], x, A, B, N, 128, st);
+    if (net.n_in == 4) rc = g->opt_first_split == 2 ? launch_conv<4, 128, 5, 4, true, false, 2>(g, 0, net.L[0], x, A, B, N, 128, st)
+                       : g->opt_first_split == 4 ? launch_conv<4, 128, 5, 4, true, false, 4>(g, 0, net.L[0], x, A, B, N, 128, st)
+                                                 : launch_conv<4, 128, 5, 4, true, false, 1>(g, 0, net.L[0], x, A, B, N, 128, st);
+    else rc = g->opt_first_split == 2 ? launch_conv<2, 128, 5, 2, true, false, 2>(g, 0, net.L[0], x, A, B, N, 128, st)
+            : g->opt_first_split == 4 ? launch_conv<2, 128, 5, 2, true, false, 4>(g, 0, net.L[0], x, A, B, N, 128, st)
+                                      : launch_conv<2, 128, 5, 2, true, false, 1>(g, 0, net.L[0], x, A, B, N, 128, st);
     if (rc) return rc;
     if ((rc = conv_hidden<128, 64, 5>(g, 1, net.L[1], A, Bb, B, N, st))) return rc;
     if ((rc = conv_hidden<64, 32, 3>(g, 2, net.L[2], Bb, A, B, N, st))) return rc;
@@ -938,7 +949,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
     for (int n = 0; n < 2; ++n)
         for (int li = 0; li < 8; ++li) {
             LayerHost &L = g->nets[n].L[li];
-            float *ptrs[] = {L.w, L.w32, L.bias, L.scale, L.shift};
+            float *ptrs[] = {L.w, L.w32, L.wl16, L.bias, L.scale, L.shift};
             for (float *p : ptrs) if (p) (void)hipFree(p);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1};
@@ -986,9 +997,9 @@ extern "C" int qgx_generator_profile_read(qgx_generator *g, double *total_ms, in
 extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int value) {
     QGX_REQUIRE(g && name, "qgx_generator_set_option: null argument");
     if (!strcmp(name, "chunk")) { QGX_REQUIRE(value == 16 || value == 32, "chunk must be 16 or 32"); g->opt_cc = value; }
-    else if (!strcmp(name, "stage_batched")) g->opt_stage = value;   // 1 = batched; 2..5 = timing-only ablations
-    else if (!strcmp(name, "persistent")) g->opt_persistent = value ? 1 : 0;
     else if (!strcmp(name, "last_valu")) g->opt_last_valu = value ? 1 : 0;
+    else if (!strcmp(name, "v3")) g->opt_v3 = value;   // -1 auto, 0 off, 1 = slice per tap row, 2 = per chunk
+    else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;
 }
