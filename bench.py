@@ -106,6 +106,8 @@ def main():
     ap.add_argument('--kind', default='gan', choices=['gan', 'vae', 'gz'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-b1', action='store_true')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'gloo' + QGX_BENCH_ONE_DEVICE=1 rehearses the multi-rank path on a 1-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -114,12 +116,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     dist = None
+    if os.environ.get('QGX_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0                      # rehearsal: every rank shares GPU 0 (gloo only)
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     import pyqg_generative_amd as qa
     N, B, K, W = args.nx, args.members, args.steps, args.warmup
@@ -148,7 +155,7 @@ def main():
     l2_ms, l2_n = gen.profile_read()
     gen.profile(-1)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ke, cfl = eng.status()

@@ -9,6 +9,7 @@
 // entirely inside one CU's LDS (N <= 96: N*(N+1)*16 B <= 149 KB).
 #include "common.hpp"
 #include "fft_lds.hpp"
+#include <cstdlib>
 
 namespace qgx {
 
@@ -271,7 +272,14 @@ static size_t small_lds_bytes(const SpecDev &d) {
     size_t bytes = (size_t)d.N * d.LD * sizeof(double2) + (size_t)d.N * sizeof(int);
     return (bytes + 15) & ~(size_t)15;
 }
-static int small_threads(const SpecDev &d) { return d.N <= 64 ? 256 : 512; }
+static int small_threads(const SpecDev &d) {
+    static const int forced = getenv("QGX_SPEC_THREADS") ? atoi(getenv("QGX_SPEC_THREADS")) : 0;   // tuning aid
+    if (forced > 0) return forced;
+    // One workgroup advances one member.  With at most one member per CU the kernel is a latency chain
+    // (about 50 barriers): 1024 threads shorten it (B=128, N=64: 119 -> 71 us); with several members
+    // queued per CU 512 threads give the best throughput (B=1024: 293 us vs 385 @256 / 337 @1024).
+    return d.B <= 256 ? 1024 : 512;
+}
 
 bool small_path_fits(int N) {
     return (size_t)N * (N + 1) * 16 + (size_t)N * 4 + 16 <= 160 * 1024;
