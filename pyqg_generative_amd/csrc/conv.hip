@@ -602,7 +602,7 @@ __global__ void k_moments(const float *y, double *sum, double *sumsq, size_t n) 
 struct LayerHost {
     int cin, cout, ks, coutp, cc, ngroups;
     LastWeights wv_host;   // last layer, VALU kernel layout (kernel argument)
-    float *wl16 = nullptr;   // k_conv3 layout [chunk][tap][g8][h][coutp][4], 16-channel chunks
+    float *wl16 = nullptr, *wl8 = nullptr;   // k_conv3 layout [chunk][tap][g8][h][coutp][4], 16- / 8-channel chunks
     float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
 };
 struct NetHost {
@@ -672,8 +672,8 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
     } else {
         if ((rc = pack_weights(L, li, w, false, 16, L.w))) return rc;
         if ((rc = pack_weights(L, li, w, false, 32, L.w32))) return rc;
-        {   // LDS-operand layout for k_conv3
-            const int cin = L.cin, ks = L.ks, T = ks * ks, cc = 16, g8n = cc / 8, nch = cin / cc;
+        for (int cc : {16, 8}) {   // LDS-operand layouts for k_conv3
+            const int cin = L.cin, ks = L.ks, T = ks * ks, g8n = cc / 8, nch = cin / cc;
             std::vector<float> pw((size_t)nch * T * g8n * 2 * L.coutp * 4, 0.f);
             for (int ch = 0; ch < nch; ++ch)
                 for (int t = 0; t < T; ++t)
@@ -685,7 +685,7 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
                                     pw[(((((size_t)ch * T + t) * g8n + g8) * 2 + hh) * L.coutp + co) * 4 + e] =
                                         w->conv_w[li][((size_t)co * cin + c) * T + t];
                                 }
-            if ((rc = upf(L.wl16, pw))) return rc;
+            if ((rc = upf(cc == 16 ? L.wl16 : L.wl8, pw))) return rc;
         }
     }
     if (li == 7) {      // [tap][c][2] for the VALU last-layer kernel
@@ -763,11 +763,11 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
 }
 
 // ---- k_conv3 launcher -------------------------------------------------------------------------
-template <int CIN, int COUT, int KS, int TPS>
+template <int CIN, int COUT, int KS, int TPS, int CC = 16>
 static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                         int N, hipStream_t st, bool &done) {
     done = false;
-    constexpr int CC = 16, T = KS * KS, NSL = T / TPS, NTc = (COUT + 31) / 32;
+    constexpr int T = KS * KS, NSL = T / TPS, NTc = (COUT + 31) / 32;
     constexpr size_t WSLB = (size_t)TPS * (CC / 8) * 2 * NTc * 32 * 4 * sizeof(float);
     // rows per tile: as k_conv (8 or 12 M-tiles), LDS = 2 patches + 2 weight slices
     const int R = choose_rows(N);
@@ -781,7 +781,7 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
     ConvArgs a;
-    a.in = in; a.out = out; a.w = L.wl16; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.in = in; a.out = out; a.w = CC == 16 ? L.wl16 : L.wl8; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = COUT;
     const int total_tiles = B * (N / R);
     const int wgs = lds * 2 <= 160 * 1024 ? 2 : 1;
@@ -815,6 +815,7 @@ static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const fl
     if (v3) {
         bool done;
         int rc = v3 == 2 ? launch_conv3<CIN, COUT, KS, KS * KS>(g, layer, L, in, out, B, N, st, done)
+               : v3 == 3 ? launch_conv3<CIN, COUT, KS, KS, 8>(g, layer, L, in, out, B, N, st, done)
                          : launch_conv3<CIN, COUT, KS, KS>(g, layer, L, in, out, B, N, st, done);
         if (rc || done) return rc;
     }
@@ -949,7 +950,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
     for (int n = 0; n < 2; ++n)
         for (int li = 0; li < 8; ++li) {
             LayerHost &L = g->nets[n].L[li];
-            float *ptrs[] = {L.w, L.w32, L.wl16, L.bias, L.scale, L.shift};
+            float *ptrs[] = {L.w, L.w32, L.wl16, L.wl8, L.bias, L.scale, L.shift};
             for (float *p : ptrs) if (p) (void)hipFree(p);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1};
