@@ -33,11 +33,12 @@ struct ConvArgs {
     const float *w;        // packed [kgroup][COUTP][8]
     const float *bias, *scale, *shift;   // [COUTP]
     int N, R, cout_real;
+    size_t npix_total;     // B*N*N (stride of one split-K partial plane)
 };
 
 extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
-template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL, int CSPLIT = 1>
+template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL, int CSPLIT = 1, bool PARTIAL = false>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     constexpr int NTF = (COUT + 31) / 32;        // all output-channel tiles of the layer
     constexpr int NT = NTF / CSPLIT;             // tiles owned by this workgroup (blockIdx.y picks the slice)
@@ -127,7 +128,16 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         constexpr int G8 = CC / 8;
         constexpr int C4 = CC / 4;
         const float4 *wp = reinterpret_cast<const float4 *>(a.w) + (size_t)li * 2 + h;
-        for (int c0 = 0; c0 < CIN; c0 += CC) {
+        // split-K (small ensembles): blockIdx.y owns a contiguous range of input-channel chunks and
+        // stores raw partial sums; k_conv_reduce adds them in a fixed order and applies the epilogue
+        int cbeg = 0, cend = CIN;
+        if constexpr (PARTIAL) {
+            const int per = CIN / (int)gridDim.y;
+            cbeg = blockIdx.y * per;
+            cend = cbeg + per;
+            wp += (size_t)(cbeg / CC) * T * G8 * COUTP * 2;
+        }
+        for (int c0 = cbeg; c0 < cend; c0 += CC) {
             __syncthreads();
             // ---- stage patch chunk: (PR rows) x N x CC channels, pixel stride CC+4 floats
             for (int it = threadIdx.x; it < PR * N * C4; it += 256) {
@@ -225,6 +235,13 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
                         const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                         o[p] = acc[mt][nt][r] + bias;
                     }
+                }
+            } else if constexpr (PARTIAL) {
+                float *o = a.out + ((size_t)blockIdx.y * a.npix_total + (size_t)b * N * N + (size_t)y0 * N) * COUT + co;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    o[(size_t)p * COUT] = acc[mt][nt][r];
                 }
             } else {
                 const float sc = a.scale[co], sh = a.shift[co];
@@ -481,6 +498,27 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
 #undef QGX_W_LOAD
 #undef QGX_W_STORE
 
+// out[p][c] = BN(ReLU(sum_s partial[s][p][c] + bias[c])): deterministic split-K combine (fixed order)
+template <int COUT>
+__global__ void k_conv_reduce(const float *partial, int nsplit, size_t npix_total, const float *bias,
+                              const float *scale, const float *shift, float *out) {
+    const size_t n4 = npix_total * COUT / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % COUT);
+        float4 v = reinterpret_cast<const float4 *>(partial)[i];
+        for (int s2 = 1; s2 < nsplit; ++s2) {
+            const float4 w = reinterpret_cast<const float4 *>(partial)[(size_t)s2 * n4 + i];
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        float4 o;
+        o.x = fmaxf(v.x + bias[c + 0], 0.f) * scale[c + 0] + shift[c + 0];
+        o.y = fmaxf(v.y + bias[c + 1], 0.f) * scale[c + 1] + shift[c + 1];
+        o.z = fmaxf(v.z + bias[c + 2], 0.f) * scale[c + 2] + shift[c + 2];
+        o.w = fmaxf(v.w + bias[c + 3], 0.f) * scale[c + 3] + shift[c + 3];
+        reinterpret_cast<float4 *>(out)[i] = o;
+    }
+}
+
 // ---- last layer (32 -> n_out <= 2, 3x3): VALU kernel ---------------------------------------------
 // Two output channels would fill 2 of 32 MFMA columns; on the vector ALUs the 288x2 dot products per
 // pixel run at full useful rate: one thread per pixel, weights broadcast from scalar registers.
@@ -619,9 +657,11 @@ struct qgx_generator {
     // workspace (grown on demand, outside any captured region)
     size_t cap_elems = 0;          // capacity in units of B*N*N pixels
     float *actA = nullptr, *actB = nullptr, *X = nullptr, *Y0 = nullptr, *Y1 = nullptr;
+    float *part = nullptr;         // split-K partial sums of the small-ensemble path
+    size_t part_elems = 0;
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
     // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
-    int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1;
+    int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     int prof_layer = -1;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
     size_t prof_used = 0;
@@ -743,7 +783,7 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
     const int ntiles = R * N / 32;
     ConvArgs a;
     a.in = in; a.out = out; a.w = (!PLANAR_IN && CC == 32) ? L.w32 : L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
-    a.N = N; a.R = R; a.cout_real = cout_real;
+    a.N = N; a.R = R; a.cout_real = cout_real; a.npix_total = (size_t)B * N * N;
     constexpr int STRIDE = PLANAR_IN ? CIN : CC + 4;
     const size_t lds = (size_t)(R + KS - 1) * N * STRIDE * sizeof(float);
     QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
@@ -754,6 +794,51 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     } else {
         auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL, CSPLIT>;
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    }
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
+}
+
+// ---- small ensembles (few tiles): 4 M-tiles per workgroup (one per wave) and split-K over the
+// 32-channel chunks, so that a single member still spreads over >= 128 workgroups -----------------
+static bool small_ensemble(int B, int N) {
+    const int R = choose_rows(N);
+    return R > 0 && B * (N / R) <= 192 && N <= 128 && 128 % N == 0;      // measured crossover ~ B=13 at 64x64
+}
+
+template <int CIN, int COUT, int KS>
+static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
+                             int N, hipStream_t st) {
+    constexpr int CC = 32;
+    const int R = 128 / N;                         // 4 M-tiles of 32 pixels
+    const int nsplit = CIN >= 64 ? CIN / CC : 1;
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    const size_t npix = (size_t)B * N * N;
+    if (nsplit > 1 && g->part_elems < npix * COUT * nsplit) {
+        if (g->part) (void)hipFree(g->part);
+        g->part = nullptr; g->part_elems = 0;
+        QGX_HIP(hipMalloc((void **)&g->part, npix * COUT * nsplit * sizeof(float)));
+        g->part_elems = npix * COUT * nsplit;
+    }
+    ConvArgs a;
+    a.in = in; a.out = nsplit > 1 ? g->part : out; a.w = L.w32; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.N = N; a.R = R; a.cout_real = COUT; a.npix_total = npix;
+    const size_t lds = (size_t)(R + KS - 1) * N * (CC + 4) * sizeof(float);
+    dim3 grid(B * (N / R), nsplit), block(256);
+    if (nsplit > 1) {
+        auto kern = k_conv<CIN, COUT, KS, CC, 1, false, false, 1, true>;
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+        const size_t n4 = npix * COUT / 4;
+        hipLaunchKernelGGL(k_conv_reduce<COUT>, dim3((unsigned)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256)), dim3(256),
+                           0, st, (const float *)g->part, nsplit, npix, (const float *)L.bias, (const float *)L.scale,
+                           (const float *)L.shift, out);
+    } else {
+        auto kern = k_conv<CIN, COUT, KS, CC, 1, false, false, 1, false>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     }
@@ -811,6 +896,7 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
 template <int CIN, int COUT, int KS>
 static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                        int N, hipStream_t st) {
+    if (g->opt_small && small_ensemble(B, N)) return launch_conv_small<CIN, COUT, KS>(g, layer, L, in, out, B, N, st);
     const int v3 = g->opt_v3 >= 0 ? g->opt_v3 : (CIN <= 64 ? 1 : 0);
     if (v3) {
         bool done;
@@ -825,7 +911,8 @@ static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const fl
 
 static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *in, float *out, int B, int N,
                             int n_out, hipStream_t st) {
-    const int R = choose_rows(N);
+    int R = choose_rows(N);
+    if (g->opt_small && R > 0 && B * (N / R) <= 192) R = 1;      // small ensembles: one row per workgroup
     QGX_REQUIRE(R > 0 && N % R == 0, "generator: unsupported grid size N=%d", N);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, 7, st, prof_stop); if (prc) return prc; }
@@ -953,7 +1040,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             float *ptrs[] = {L.w, L.w32, L.wl16, L.wl8, L.bias, L.scale, L.shift};
             for (float *p : ptrs) if (p) (void)hipFree(p);
         }
-    float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1};
+    float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
     for (float *p : bufs) if (p) (void)hipFree(p);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     delete g;
@@ -999,6 +1086,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     QGX_REQUIRE(g && name, "qgx_generator_set_option: null argument");
     if (!strcmp(name, "chunk")) { QGX_REQUIRE(value == 16 || value == 32, "chunk must be 16 or 32"); g->opt_cc = value; }
     else if (!strcmp(name, "last_valu")) g->opt_last_valu = value ? 1 : 0;
+    else if (!strcmp(name, "small")) g->opt_small = value ? 1 : 0;
     else if (!strcmp(name, "v3")) g->opt_v3 = value;   // -1 auto, 0 off, 1 = slice per tap row, 2 = per chunk
     else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
