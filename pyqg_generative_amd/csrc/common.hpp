@@ -104,8 +104,14 @@ struct qgx_model {
 
 namespace qgx {
 // generator entry used by the stepper (conv.hip)
+// optional sampler update z <- a z + b xi folded into the generator's input kernel
+struct NoiseUpdate {
+    const void *xi_ext;      // external draw or nullptr (Philox)
+    uint64_t seed, member_offset, step;
+    double a, b;
+};
 int generator_forward(qgx_generator *g, const double *q, const void *z, double *S, int B, int N,
-                      int demean, hipStream_t st);
+                      int demean, hipStream_t st, const NoiseUpdate *nu);
 bool generator_noise_is_double(const qgx_generator *g);
 int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st);
 int noise_update(void *z, const void *xi_ext, bool is_double, int B, int n_per_member, uint64_t seed,

@@ -19,6 +19,7 @@
 // Lane half h consumes K indices 8g+4h .. 8g+4h+3 of every group of 8 with one 16-byte
 // read of A (LDS) and of B (packed weights, L2 resident) feeding 4 consecutive MFMAs.
 #include "common.hpp"
+#include "philox.hpp"
 #include <cmath>
 #include <new>
 
@@ -585,46 +586,71 @@ __global__ void k_prep_input(const double *q, const float *z, float *X, int n_in
     }
 }
 
-// S = double(y * y_std)   (cgan_regression.py:162)
-__global__ void k_finish_gan(const float *y, double *S, int npix, float ys0, float ys1) {
-    const int b = blockIdx.y;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * npix; i += gridDim.x * blockDim.x) {
-        const size_t o = (size_t)b * 2 * npix + i;
-        S[o] = (double)(y[o] * (i < npix ? ys0 : ys1));
+// Fused sampler update + input assembly of one online step (GAN / VAE):
+//   z <- a z + b xi  (float; xi from Philox or the external draw), X = [float(q)/x_std, z]
+// One thread per quad of 4 consecutive elements of the (2,N,N) member field.
+__global__ void k_prep_noise(const double *q, float *z, const float *xi_ext, float *X, int npix, float xs0,
+                             float xs1, uint64_t seed, uint64_t member_offset, uint64_t step, float a, float b) {
+    const int member = blockIdx.y;
+    const int quads = 2 * npix / 4;
+    const int quad = blockIdx.x * blockDim.x + threadIdx.x;
+    if (quad >= quads) return;
+    const size_t o = (size_t)member * 2 * npix + 4 * (size_t)quad;
+    float x[4];
+    if (xi_ext) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = xi_ext[o + e];
+    } else {
+        philox_normal4(seed, member_offset + member, step, (uint32_t)quad, x);
+    }
+    float *Xm = X + (size_t)member * 4 * npix;
+    const int i = 4 * quad;                          // flat index in (2, npix); npix % 4 == 0
+    const float xs = i < npix ? xs0 : xs1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float zn = a == 0.f ? b * x[e] : a * z[o + e] + b * x[e];
+        z[o + e] = zn;
+        Xm[2 * (size_t)npix + i + e] = zn;
+        Xm[i + e] = (float)q[o + e] / xs;
     }
 }
 
-// S = (mean + z * sqrt(softplus(var))) * y_std   (mean_var_model.py:14-17,105-109), z double
-__global__ void k_finish_gz(const float *ymean, const float *yvar, const double *z, double *S, int npix,
-                            float ys0, float ys1) {
-    const int b = blockIdx.y;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * npix; i += gridDim.x * blockDim.x) {
-        const size_t o = (size_t)b * 2 * npix + i;
-        const float vr = yvar[o];
-        const float sp = vr > 20.f ? vr : log1pf(expf(vr));
-        const double val = (double)ymean[o] + z[o] * (double)sqrtf(sp);
-        S[o] = val * (double)(i < npix ? ys0 : ys1);
-    }
-}
-
-// S -= mean_{y,x}(S) per (member, layer)   (parameterization.py:25)
-__global__ void k_demean(double *S, int npix) {
+// Fused output scaling + per-layer de-mean: one workgroup per (member, layer).
+//   GAN/VAE: S = double(y * y_std)                         (cgan_regression.py:162)
+//   GZ:      S = (mean + z sqrt(softplus(var))) * y_std    (mean_var_model.py:14-17,105-109)
+//   then S -= mean_{y,x} S                                 (parameterization.py:25)
+template <bool GZ>
+__global__ void k_finish(const float *y0, const float *y1, const double *z, double *S, int npix, float ys0,
+                         float ys1, int demean) {
     __shared__ double sm[16];
     __shared__ double mean_s;
-    double *s = S + (size_t)blockIdx.x * npix;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < npix; i += blockDim.x) acc += s[i];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
-        mean_s = t / (double)npix;
+    const size_t o = (size_t)blockIdx.x * npix;
+    const float ys = (blockIdx.x & 1) ? ys1 : ys0;
+    auto value = [&](int i) -> double {
+        if constexpr (GZ) {
+            const float vr = y1[o + i];
+            const float sp = vr > 20.f ? vr : log1pf(expf(vr));
+            return ((double)y0[o + i] + z[o + i] * (double)sqrtf(sp)) * (double)ys;
+        } else {
+            return (double)(y0[o + i] * ys);
+        }
+    };
+    double mu = 0.0;
+    if (demean) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < npix; i += blockDim.x) acc += value(i);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+            mean_s = t / (double)npix;
+        }
+        __syncthreads();
+        mu = mean_s;
     }
-    __syncthreads();
-    const double mu = mean_s;
-    for (int i = threadIdx.x; i < npix; i += blockDim.x) s[i] -= mu;
+    for (int i = threadIdx.x; i < npix; i += blockDim.x) S[o + i] = value(i) - mu;
 }
 
 // running first and second moments over Monte-Carlo samples (generate_mean_var, cgan_regression.py:139-146)
@@ -971,25 +997,34 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
 bool generator_noise_is_double(const qgx_generator *g) { return g->kind == QGX_GEN_GZ; }
 
 int generator_forward(qgx_generator *g, const double *q, const void *z, double *S, int B, int N,
-                      int demean, hipStream_t st) {
+                      int demean, hipStream_t st, const NoiseUpdate *nu) {
     QGX_REQUIRE(g && q && z && S && B > 0, "generator_forward: bad argument");
     int rc = reserve(g, B, N);
     if (rc) return rc;
     const int npix = N * N;
+    QGX_REQUIRE(npix % 4 == 0, "generator_forward: N*N must be a multiple of 4");
     dim3 pg((npix + 255) / 256, B), pb(256);
     if (g->kind == QGX_GEN_GZ) {
+        if (nu && (rc = noise_update(const_cast<void *>(z), nu->xi_ext, true, B, 2 * npix, nu->seed, nu->member_offset,
+                                     nu->step, nu->a, nu->b, st))) return rc;
         hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)nullptr, g->X, 2, npix, g->x_std[0], g->x_std[1]);
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
         if ((rc = cnn_forward(g, g->nets[1], g->X, g->Y1, B, N, st))) return rc;
-        dim3 fg((2 * npix + 255) / 256, B);
-        hipLaunchKernelGGL(k_finish_gz, fg, pb, 0, st, g->Y0, g->Y1, (const double *)z, S, npix, g->y_std[0], g->y_std[1]);
+        hipLaunchKernelGGL(k_finish<true>, dim3(2 * B), dim3(256), 0, st, (const float *)g->Y0, (const float *)g->Y1,
+                           (const double *)z, S, npix, g->y_std[0], g->y_std[1], demean);
     } else {
-        hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)z, g->X, 4, npix, g->x_std[0], g->x_std[1]);
+        if (nu) {
+            dim3 qg((2 * npix / 4 + 255) / 256, B);
+            hipLaunchKernelGGL(k_prep_noise, qg, pb, 0, st, q, (float *)const_cast<void *>(z), (const float *)nu->xi_ext,
+                               g->X, npix, g->x_std[0], g->x_std[1], nu->seed, nu->member_offset, nu->step,
+                               (float)nu->a, (float)nu->b);
+        } else {
+            hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)z, g->X, 4, npix, g->x_std[0], g->x_std[1]);
+        }
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
-        dim3 fg((2 * npix + 255) / 256, B);
-        hipLaunchKernelGGL(k_finish_gan, fg, pb, 0, st, g->Y0, S, npix, g->y_std[0], g->y_std[1]);
+        hipLaunchKernelGGL(k_finish<false>, dim3(2 * B), dim3(256), 0, st, (const float *)g->Y0, (const float *)nullptr,
+                           (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean);
     }
-    if (demean) hipLaunchKernelGGL(k_demean, dim3(2 * B), dim3(256), 0, st, S, npix);
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
@@ -1049,7 +1084,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
 
 extern "C" int qgx_generator_forward(qgx_generator *g, const double *q_dev, const void *z_dev, double *S_dev,
                                      int B, int N, int demean, void *stream) {
-    return generator_forward(g, q_dev, z_dev, S_dev, B, N, demean, (hipStream_t)stream);
+    return generator_forward(g, q_dev, z_dev, S_dev, B, N, demean, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int qgx_cnn_forward(qgx_generator *g, int inet, const float *x_dev, float *y_dev, int B, int N,

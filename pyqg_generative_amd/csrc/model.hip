@@ -374,16 +374,16 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
                     else { m->const_counter += 1; compute = false; draw = false; }
                 } else m->const_counter = 1;
             }
+            NoiseUpdate nu;
             if (draw) {
-                const int npm = 2 * N * N;
-                int rc = noise_update(m->z, p->z_external_dev, m->z_double, B, npm, p->seed,
-                                      p->member_offset, m->noise_step, a, b, st);
-                if (rc) return rc;
+                nu.xi_ext = p->z_external_dev; nu.seed = p->seed; nu.member_offset = p->member_offset;
+                nu.step = m->noise_step; nu.a = a; nu.b = b;
                 m->noise_step += 1;
                 m->have_noise = true;
             }
             if (compute) {
-                int rc = generator_forward(p->gen, m->q, m->z, m->S, B, N, p->demean, st);
+                // a redraw always comes with a recompute; the sampler update rides in the input kernel
+                int rc = generator_forward(p->gen, m->q, m->z, m->S, B, N, p->demean, st, draw ? &nu : nullptr);
                 if (rc) return rc;
                 m->have_forcing = true;
             }

@@ -274,3 +274,23 @@ def test_on_device_noise_run_is_reproducible_and_member_streams_differ():
     e.set_q(q0[:2])
     e.step(6, generator=gen, sampling='AR1', nsteps_decor=1, seed=42, member_offset=2)
     assert torch.equal(e.get(L.F_Q), outs[0][2:])
+
+
+def test_fused_step_noise_follows_pinned_philox_stream():
+    """The sampler update folded into the generator's input kernel draws the same Philox stream as
+    qgx_noise_normal / the oracle: z after steps 0 and 1 of an AR1(nsteps=2) run."""
+    import pyqg_generative_amd._lib as L
+    N, B, seed, off = 64, 3, 99, 5
+    gen = _gpu_generator('vae')
+    e = _engine(N, B, dt=14400.)
+    e.set_q(_eddy_like_q(np.random.RandomState(0), B, N))
+    e.step(1, generator=gen, sampling='AR1', nsteps_decor=2, seed=seed, member_offset=off)
+    z0 = e.get(L.F_Z).cpu().numpy().reshape(B, -1)
+    e.step(1, generator=gen, sampling='AR1', nsteps_decor=2, seed=seed, member_offset=off)
+    z1 = e.get(L.F_Z).cpu().numpy().reshape(B, -1)
+    a, b = np.float32(1 - 1 / 2), np.float32((1 / 2 * (2 - 1 / 2)) ** 0.5)
+    for m in range(B):
+        x0, _ = samplers_ref.philox_normal(seed, off + m, 0, 2 * N * N)
+        x1, _ = samplers_ref.philox_normal(seed, off + m, 1, 2 * N * N)
+        assert np.abs(z0[m] - x0).max() < 2e-5
+        assert np.abs(z1[m] - (a * x0 + b * x1)).max() < 4e-5
