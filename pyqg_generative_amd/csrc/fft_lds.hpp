@@ -4,7 +4,7 @@
 // digit-reversed order out.  Inverse = the transposed flow graph
 // (decimation-in-time, conjugate twiddles), digit-reversed in -> natural out.
 // Spectral-space code addresses coefficients through SpecDev::pos[], so no
-// reordering pass is ever executed.  Radices 2, 3, 4.
+// reordering pass is ever executed.  Radices 2, 3, 4, 8.
 //
 // A "line" is one 1-D transform of length N living in LDS at
 //   base + line * line_stride + e * elem_stride      (units: double2)
@@ -45,6 +45,27 @@ __device__ __forceinline__ void small_dft(double2 (&v)[R]) {
         v[1] = cadd(d02, r);
         v[2] = csub(s02, s13);
         v[3] = csub(d02, r);
+    } else if constexpr (R == 8) {
+        // two interleaved radix-4 transforms (even / odd inputs) + one radix-2 stage with W8^k
+        double2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+        small_dft<4, FWD>(e);
+        small_dft<4, FWD>(o);
+        const double h = 0.70710678118654752440;
+        // W8^1 = (1 -+ i)/sqrt2, W8^2 = -+ i, W8^3 = (-1 -+ i)/sqrt2   (upper sign: forward)
+        double2 t1, t2, t3;
+        if (FWD) {
+            t1 = make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));
+            t2 = mul_mi(o[2]);
+            t3 = make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));
+        } else {
+            t1 = make_double2(h * (o[1].x - o[1].y), h * (o[1].y + o[1].x));
+            t2 = mul_pi(o[2]);
+            t3 = make_double2(-h * (o[3].x + o[3].y), h * (o[3].x - o[3].y));
+        }
+        v[0] = cadd(e[0], o[0]); v[4] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], t1);   v[5] = csub(e[1], t1);
+        v[2] = cadd(e[2], t2);   v[6] = csub(e[2], t2);
+        v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
     } else {  // R == 3
         const double c = -0.5, s = 0.86602540378443864676;   // cos, sin of 2 pi / 3
         double2 t = cadd(v[1], v[2]);
@@ -93,7 +114,8 @@ __device__ __forceinline__ void fft_pass(double2 *Z, int nl, int ls, int es, int
 template <bool FWD>
 __device__ __forceinline__ void fft_pass_any(int R, double2 *Z, int nl, int ls, int es, int n, int N,
                                              const double2 *__restrict__ tw) {
-    if (R == 4) fft_pass<4, FWD>(Z, nl, ls, es, n, N, tw);
+    if (R == 8) fft_pass<8, FWD>(Z, nl, ls, es, n, N, tw);
+    else if (R == 4) fft_pass<4, FWD>(Z, nl, ls, es, n, N, tw);
     else if (R == 2) fft_pass<2, FWD>(Z, nl, ls, es, n, N, tw);
     else fft_pass<3, FWD>(Z, nl, ls, es, n, N, tw);
 }

@@ -63,6 +63,7 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
 static bool factor_radices(int N, int *rad, int &nrad) {
     nrad = 0;
     int n = N;
+    while (n % 8 == 0) { rad[nrad++] = 8; n /= 8; }
     while (n % 4 == 0) { rad[nrad++] = 4; n /= 4; }
     while (n % 2 == 0) { rad[nrad++] = 2; n /= 2; }
     while (n % 3 == 0) { rad[nrad++] = 3; n /= 3; }

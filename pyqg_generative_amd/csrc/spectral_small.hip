@@ -278,7 +278,8 @@ static int small_threads(const SpecDev &d) {
     // One workgroup advances one member.  With at most one member per CU the kernel is a latency chain
     // (about 50 barriers): 1024 threads shorten it (B=128, N=64: 119 -> 71 us); with several members
     // queued per CU 512 threads give the best throughput (B=1024: 293 us vs 385 @256 / 337 @1024).
-    return d.B <= 256 ? 1024 : 512;
+    // Grids above 64x64 leave room for one workgroup per CU only: always 1024 threads there.
+    return (d.B <= 256 || d.N > 64) ? 1024 : 512;
 }
 
 bool small_path_fits(int N) {
