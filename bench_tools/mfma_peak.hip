@@ -1,43 +1,67 @@
-// Developer tool: the f32 MFMA rate this device actually sustains (bare v_mfma_f32_32x32x2_f32 loop,
-// operands in registers, 4 independent accumulators per wave), to put the conv kernels' numbers in
-// context.  Build + run on the GPU box: hipcc --offload-arch=gfx950 -O3 mfma_peak.hip -o /tmp/mfma_peak
+// Developer tool: what f32 MFMA rate and shader clock does this device sustain when the MFMA stream is
+// accompanied by the operand traffic of the conv kernels?  v_mfma_f32_32x32x2_f32, 4 accumulators/wave.
+//   mode 0: operands in registers (random values)         mode 1: + 4 ds_read_b128 per 16 MFMAs
+//   mode 2: + 2 global_load_dwordx4 per 16 MFMAs (L2-resident 1 MB table)     mode 3: both
+// hipcc --offload-arch=gfx950 -O3 mfma_peak.hip -o /tmp/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(256) void k(float *out, int iters, float a0, float b0) {
+__global__ __launch_bounds__(256) void k(float *out, const float4 *tab, int iters, int mode, unsigned long long *clk) {
+    __shared__ float4 lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        unsigned x = (i * 2654435761u) ^ 0x9E3779B9u;
+        lds[i] = make_float4((x & 1023) * 1e-3f - 0.5f, ((x >> 10) & 1023) * 1e-3f - 0.5f, ((x >> 20) & 1023) * 1e-3f - 0.5f, 0.25f);
+    }
+    __syncthreads();
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    // RANDOM operands (16 distinct registers per lane, uniform [-1,1)): trivial operands read high (DVFS)
-    float av[16], bv[16];
-    unsigned x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
-    for (int i = 0; i < 16; ++i) {
-        x = x * 1664525u + 1013904223u; av[i] = (a0 != 0.f) ? ((x >> 8) * (2.0f / 16777216.0f) - 1.0f) : 0.5f;
-        x = x * 1664525u + 1013904223u; bv[i] = (a0 != 0.f) ? ((x >> 8) * (2.0f / 16777216.0f) - 1.0f) : 0.25f;
-    }
+    float4 A[2], Bv[2];
+    A[0] = lds[threadIdx.x]; A[1] = lds[threadIdx.x + 256]; Bv[0] = lds[threadIdx.x + 512]; Bv[1] = lds[threadIdx.x + 768];
+    unsigned long long t0 = 0, r0 = 0;
+    if (threadIdx.x == 0) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    int li = threadIdx.x;
+    const float4 *gp = tab + threadIdx.x;
     for (int it = 0; it < iters; ++it) {
+        float4 An[2] = {A[0], A[1]}, Bn[2] = {Bv[0], Bv[1]};
+        if (mode & 1) {
+            An[0] = lds[(li + it * 64) & 4095]; An[1] = lds[(li + it * 64 + 1024) & 4095];
+            Bn[0] = lds[(li + it * 64 + 2048) & 4095]; Bn[1] = lds[(li + it * 64 + 3072) & 4095];
+        }
+        if (mode & 2) { Bn[0] = gp[(it * 256) & 65535]; Bn[1] = gp[(it * 256 + 128) & 65535]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u * 4 + i], bv[(u * 4 + i + 5) & 15], acc[i], 0, 0, 0);
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m * 2 + n] = __builtin_amdgcn_mfma_f32_32x32x2f32((&A[m].x)[e], (&Bv[n].x)[e], acc[m * 2 + n], 0, 0, 0);
+        A[0] = An[0]; A[1] = An[1]; Bv[0] = Bn[0]; Bv[1] = Bn[1];
     }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - t0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
     float s = 0;
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 int main() {
     float *d; hipMalloc(&d, 4096 * 256 * 4);
-    for (int mode = 0; mode < 2; ++mode)
-    for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu) {
-        const int grid = 256 * wg_per_cu, iters = 40000;
-        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int rep = 0; rep < 3; ++rep) {
-            hipEventRecord(e0);
-            hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, d, iters, mode ? 1.0f : 0.0f, 0.25f);
-            hipEventRecord(e1); hipEventSynchronize(e1);
-            float ms; hipEventElapsedTime(&ms, e0, e1);
+    float4 *tab; hipMalloc(&tab, 65536 * 16 + 4096 * 16); hipMemset(tab, 0x3c, 65536 * 16 + 4096 * 16);
+    unsigned long long *clk; hipMalloc(&clk, 16);
+    for (int mode = 0; mode < 4; ++mode)
+        for (int wg_per_cu = 1; wg_per_cu <= 2; ++wg_per_cu) {
+            const int grid = 256 * wg_per_cu, iters = 40000;
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            float best = 1e9; unsigned long long h[2] = {0, 0};
+            for (int rep = 0; rep < 3; ++rep) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, 0, d, (const float4 *)tab, iters, mode, clk);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) { best = ms; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost); }
+            }
             const double flop = (double)grid * 4 * iters * 16 * 4096.0;
-            printf("%s wg/cu=%d rep=%d: %.3f ms  %.1f TFLOP/s\n", mode ? "random  " : "constant", wg_per_cu, rep, ms, flop / ms / 1e9);
+            printf("mode %d wg/cu=%d: %.3f ms  %.1f TFLOP/s  shader clock %.0f MHz\n", mode, wg_per_cu, best, flop / best / 1e9,
+                   h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0);
         }
-    }
     return 0;
 }

@@ -266,8 +266,9 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 // LDS buffers at its end, so the K loop contains no vector-memory instruction and nothing ever waits
 // on HBM/L2 latency except the stage boundary.  The workgroup is persistent over its tiles, so the
 // prefetch also runs across tile boundaries; one barrier per stage.
-template <int CIN, int COUT, int KS, int CC, int MT, int TPS, int PPT>
-__global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
+template <int CIN, int COUT, int KS, int CC, int MT, int TPS, int PPT, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_conv3(ConvArgs a, int total_tiles) {
+    constexpr int NTHR = NW * 64;
     constexpr int NT = (COUT + 31) / 32;
     constexpr int COUTP = NT * 32;
     constexpr int P = KS / 2;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
     constexpr int NSL = T / TPS;                        // weight slices per chunk
     constexpr int WSL = TPS * G8 * 2 * COUTP * 4;       // floats per slice, layout [tap][g8][h][cout][4]
     constexpr int WF4 = WSL / 4;
-    constexpr int WPT = (WF4 + 255) / 256;
+    constexpr int WPT = (WF4 + NTHR - 1) / NTHR;
     static_assert(T % TPS == 0, "taps per slice must divide the tap count");
     const int N = a.N, R = a.R;
     const int PR = R + KS - 1;
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
         const int b_ = tile_ / tiles_per_img;                                                               \
         const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
-            int it_ = (LO) + u * 256 + threadIdx.x;                                                         \
+            int it_ = (LO) + u * NTHR + threadIdx.x;                                                         \
             it_ = it_ < (HI) ? it_ : (HI) - 1; /* clamped: branch-free, the store is predicated instead */  \
             const int c4_ = it_ % C4, pl_ = it_ / C4;                                                       \
             const int pr_ = pl_ / N, x_ = pl_ - pr_ * N;                                                    \
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
 #define QGX_PATCH_STORE(BUF, LO, HI, V)                                                                     \
     {                                                                                                       \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
-            const int it_ = (LO) + u * 256 + threadIdx.x;                                                   \
+            const int it_ = (LO) + u * NTHR + threadIdx.x;                                                   \
             if (it_ < (HI)) {                                                                               \
                 const int c4_ = it_ % C4, pl_ = it_ / C4;                                                   \
                 *reinterpret_cast<f32x4 *>(&(BUF)[pl_ * STRIDE + c4_ * 4]) = V[u];                          \
@@ -329,14 +330,14 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
     {                                                                                                       \
         const f32x4 *src_ = reinterpret_cast<const f32x4 *>(a.w) + ((size_t)(CH) * NSL + (SL)) * WF4;       \
         _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
-            const int it_ = u * 256 + threadIdx.x;                                                          \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
             V[u] = src_[it_ < WF4 ? it_ : WF4 - 1];                                                         \
         }                                                                                                   \
     }
 #define QGX_W_STORE(BUF, V)                                                                                 \
     {                                                                                                       \
         _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
-            const int it_ = u * 256 + threadIdx.x;                                                          \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
             if (it_ < WF4) reinterpret_cast<f32x4 *>(BUF)[it_] = V[u];                                      \
         }                                                                                                   \
     }
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
     // ---- prologue: first chunk's patch and first weight slice, synchronously
     {
         f32x4 pv[PPT];
-        for (int lo = 0; lo < PF4; lo += PPT * 256) {
-            const int hi = lo + PPT * 256 < PF4 ? lo + PPT * 256 : PF4;
+        for (int lo = 0; lo < PF4; lo += PPT * NTHR) {
+            const int hi = lo + PPT * NTHR < PF4 ? lo + PPT * NTHR : PF4;
             QGX_PATCH_LOAD(0, 0, lo, hi, pv)
             QGX_PATCH_STORE(lds0, lo, hi, pv)
         }
@@ -359,8 +360,8 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
     int py[MT], px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int tile = wave + 4 * mt;
-        if (tile >= ntiles) tile = wave;
+        int tile = wave + NW * mt;
+        if (tile >= ntiles) tile = wave % ntiles;
         const int p = tile * 32 + li;
         py[mt] = p / N;
         px[mt] = p - py[mt] * N;
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void k_conv3(ConvArgs a, int total_tiles) {
                     const int y0 = (tile_g - b * tiles_per_img) * R;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        const int tile = wave + 4 * mt;
+                        const int tile = wave + NW * mt;
                         if (tile >= ntiles) continue;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
@@ -738,7 +739,7 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
     } else {
         if ((rc = pack_weights(L, li, w, false, 16, L.w))) return rc;
         if ((rc = pack_weights(L, li, w, false, 32, L.w32))) return rc;
-        for (int cc : {16, 8}) {   // LDS-operand layouts for k_conv3
+        for (int cc : {16}) {      // LDS-operand layout for k_conv3
             const int cin = L.cin, ks = L.ks, T = ks * ks, g8n = cc / 8, nch = cin / cc;
             std::vector<float> pw((size_t)nch * T * g8n * 2 * L.coutp * 4, 0.f);
             for (int ch = 0; ch < nch; ++ch)
@@ -874,7 +875,7 @@ static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, co
 }
 
 // ---- k_conv3 launcher -------------------------------------------------------------------------
-template <int CIN, int COUT, int KS, int TPS, int CC = 16>
+template <int CIN, int COUT, int KS, int TPS, int CC = 16, int NW = 4>
 static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                         int N, hipStream_t st, bool &done) {
     done = false;
@@ -888,7 +889,7 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
     const size_t lds = (size_t)2 * PR * N * (CC + 4) * sizeof(float) + 2 * WSLB;
     if (lds > 160 * 1024 - 256) return QGX_OK;
     const int PF4 = PR * N * (CC / 4);
-    const int ppt = (((PF4 + NSL - 1) / NSL) + 255) / 256;
+    const int ppt = (((PF4 + NSL - 1) / NSL) + NW * 64 - 1) / (NW * 64);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
     ConvArgs a;
@@ -900,12 +901,14 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
     if (grid > total_tiles) grid = total_tiles;
 #define QGX_L3(MTV, PPTV)                                                                                     \
     {                                                                                                         \
-        auto kern = k_conv3<CIN, COUT, KS, CC, MTV, TPS, PPTV>;                                               \
+        auto kern = k_conv3<CIN, COUT, KS, CC, MTV, TPS, PPTV, NW>;                                           \
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);                             \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);                         \
     }
-    const int mtv = ntiles <= 8 ? 2 : 3;
-    if (ppt <= 2) { if (mtv == 2) QGX_L3(2, 2) else QGX_L3(3, 2) }
+    const int mtv = (ntiles + NW - 1) / NW <= 1 ? 1 : ((ntiles + NW - 1) / NW == 2 ? 2 : 3);
+    if (mtv == 1) {
+        if (ppt <= 2) QGX_L3(1, 2) else if (ppt <= 4) QGX_L3(1, 4) else return QGX_OK;
+    } else if (ppt <= 2) { if (mtv == 2) QGX_L3(2, 2) else QGX_L3(3, 2) }
     else if (ppt <= 4) { if (mtv == 2) QGX_L3(2, 4) else QGX_L3(3, 4) }
     else if (ppt <= 8) { if (mtv == 2) QGX_L3(2, 8) else QGX_L3(3, 8) }
     else return QGX_OK;
@@ -927,7 +930,6 @@ static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const fl
     if (v3) {
         bool done;
         int rc = v3 == 2 ? launch_conv3<CIN, COUT, KS, KS * KS>(g, layer, L, in, out, B, N, st, done)
-               : v3 == 3 ? launch_conv3<CIN, COUT, KS, KS, 8>(g, layer, L, in, out, B, N, st, done)
                          : launch_conv3<CIN, COUT, KS, KS>(g, layer, L, in, out, B, N, st, done);
         if (rc || done) return rc;
     }
