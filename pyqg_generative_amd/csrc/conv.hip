@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int tile = wave + 4 * mt;
-        if (tile >= ntiles) tile = wave;           // duplicate work, never stored
+        if (tile >= ntiles) tile = 0;              // duplicate work on a valid tile, never stored
         const int p = tile * 32 + li;
         py[mt] = p / N;
         px[mt] = p - py[mt] * N;
@@ -831,16 +831,26 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
 
 // ---- small ensembles (few tiles): 4 M-tiles per workgroup (one per wave) and split-K over the
 // 32-channel chunks, so that a single member still spreads over >= 128 workgroups -----------------
+// rows per workgroup of the small-ensemble path: at most 4 M-tiles of 32 pixels (one per wave), as many as fit
+static int rows_small(int N) {
+    int best = 0;
+    for (int R = 1; R <= N; ++R) {
+        if (N % R || (R * N) % 32) continue;
+        if (R * N / 32 > 4) break;
+        best = R;
+    }
+    return best;
+}
 static bool small_ensemble(int B, int N) {
     const int R = choose_rows(N);
-    return R > 0 && B * (N / R) <= 192 && N <= 128 && 128 % N == 0;      // measured crossover ~ B=13 at 64x64
+    return R > 0 && B * (N / R) <= 192 && rows_small(N) > 0 && rows_small(N) < R;   // crossover ~ B=13 at 64x64
 }
 
 template <int CIN, int COUT, int KS>
 static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                              int N, hipStream_t st) {
     constexpr int CC = 32;
-    const int R = 128 / N;                         // 4 M-tiles of 32 pixels
+    const int R = rows_small(N);                   // <= 4 M-tiles of 32 pixels
     const int nsplit = CIN >= 64 ? CIN / CC : 1;
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
