@@ -231,7 +231,7 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
     m->small = small_path_fits(N);
     if (m->small) rc = small_prepare(d);
     else {
-        rc = dalloc(m->zbuf, (size_t)B * 2 * N * N);
+        rc = dalloc(m->zbuf, (size_t)B * 3 * N * N);   // 3 complex work fields per member (spectral_large.hip ZF)
         if (!rc) rc = large_prepare(d);
     }
     if (rc) { qgx_destroy(m); return rc; }

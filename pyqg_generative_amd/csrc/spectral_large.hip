@@ -10,17 +10,20 @@
 // pyqg_generative/tools/simulate.py:83-88 — the 256^2 forcing-dataset runs).
 #include "common.hpp"
 #include "fft_lds.hpp"
+#include <cstdlib>
 
 namespace qgx {
+
+constexpr int ZF = 3;   // complex N x N work fields per member in zbuf: layers 0,1 and one scratch (S / q pair)
 
 extern __shared__ __attribute__((aligned(16))) char lg_smem[];
 
 __device__ __forceinline__ int neg_mod_l(int j, int N) { return j == 0 ? 0 : N - j; }
 
 // ---- batched 1-D FFT along x (ALONG_Y = false) or y (true) of `nf` complex N x N fields -------
-// field f lives at base + f * fstride (double2 units).  One workgroup transforms LPB lines.
+// The fields are zbuf[b][k0 .. k0+nfpm) for every member b.  One workgroup transforms LPB lines.
 template <bool FWD, bool ALONG_Y>
-__global__ void k_lines_fft(SpecDev d, double2 *base, size_t fstride, int LPB) {
+__global__ void k_lines_fft(SpecDev d, double2 *base, int k0, int nfpm, int LPB) {
     double2 *L = reinterpret_cast<double2 *>(lg_smem);
     const int N = d.N, LD = N + 1;
     int *pos = reinterpret_cast<int *>(L + (size_t)LPB * LD);
@@ -28,7 +31,7 @@ __global__ void k_lines_fft(SpecDev d, double2 *base, size_t fstride, int LPB) {
     const int groups = N / LPB;
     const int f = blockIdx.x / groups;
     const int l0 = (blockIdx.x - f * groups) * LPB;
-    double2 *g = base + (size_t)f * fstride;
+    double2 *g = base + ((size_t)(f / nfpm) * ZF + k0 + f % nfpm) * N * N;
     __syncthreads();
     // stage in: element e of line l -> L[l*LD + (FWD ? e : pos[e])]
     for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
@@ -88,7 +91,7 @@ __global__ void k_l_build_uv(SpecDev d, const double2 *qh, double2 *zbuf, double
                 uh = make_double2(0.5 * (uh.x + um.x), 0.5 * (uh.y - um.y));
                 vh = make_double2(0.5 * (vh.x + vm.x), 0.5 * (vh.y - vm.y));
             }
-            pack_store_l(zbuf + ((size_t)b * 2 + k) * N * N, N, j, i, uh, vh, d.invN2);
+            pack_store_l(zbuf + ((size_t)b * ZF + k) * N * N, N, j, i, uh, vh, d.invN2);
         }
     }
 }
@@ -106,7 +109,7 @@ __global__ void k_l_build_pair(SpecDev d, const double2 *src, double2 *zbuf) {
             a = make_double2(0.5 * (a.x + am.x), 0.5 * (a.y - am.y));
             bb = make_double2(0.5 * (bb.x + bm.x), 0.5 * (bb.y - bm.y));
         }
-        pack_store_l(zbuf + (size_t)b * 2 * N * N, N, j, i, a, bb, d.invN2);
+        pack_store_l(zbuf + (size_t)b * ZF * N * N, N, j, i, a, bb, d.invN2);
     }
 }
 
@@ -114,14 +117,14 @@ __global__ void k_l_build_pair(SpecDev d, const double2 *src, double2 *zbuf) {
 __global__ void k_l_pack_real(SpecDev d, const double *r, double2 *zbuf, double w) {
     const int rz = d.N * d.N, b = blockIdx.y;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rz; idx += gridDim.x * blockDim.x)
-        zbuf[(size_t)b * 2 * rz + idx] = make_double2(w * r[(size_t)b * 2 * rz + idx], w * r[(size_t)b * 2 * rz + rz + idx]);
+        zbuf[(size_t)b * ZF * rz + idx] = make_double2(w * r[(size_t)b * 2 * rz + idx], w * r[(size_t)b * 2 * rz + rz + idx]);
 }
 
 // r[b][0], r[b][1] <- Re, Im of zbuf[b][0]
 __global__ void k_l_unpack_real(SpecDev d, const double2 *zbuf, double *r) {
     const int rz = d.N * d.N, b = blockIdx.y;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < rz; idx += gridDim.x * blockDim.x) {
-        const double2 w = zbuf[(size_t)b * 2 * rz + idx];
+        const double2 w = zbuf[(size_t)b * ZF * rz + idx];
         r[(size_t)b * 2 * rz + idx] = w.x;
         r[(size_t)b * 2 * rz + rz + idx] = w.y;
     }
@@ -130,7 +133,7 @@ __global__ void k_l_unpack_real(SpecDev d, const double2 *zbuf, double *r) {
 // dst[b][0], dst[b][1] <- half spectra of the two real fields packed in zbuf[b][0] (after fwd FFT)
 __global__ void k_l_unpack_pair(SpecDev d, const double2 *zbuf, double2 *dst, int zero_mean) {
     const int N = d.N, NK = d.NK, sz = N * NK, b = blockIdx.y;
-    const double2 *Z = zbuf + (size_t)b * 2 * N * N;
+    const double2 *Z = zbuf + (size_t)b * ZF * N * N;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < sz; idx += gridDim.x * blockDim.x) {
         const int j = idx / NK, i = idx - j * NK;
         const double2 a = Z[(size_t)j * N + i];
@@ -148,11 +151,11 @@ __global__ void k_l_products(SpecDev d, double2 *zbuf, const double *q, double *
     const int rz = d.N * d.N, b = blockIdx.y;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < 2 * rz; idx += gridDim.x * blockDim.x) {
         const int k = idx / rz;
-        const size_t o = (size_t)b * 2 * rz + idx;
-        const double2 uv = zbuf[o];
+        const size_t o = (size_t)b * 2 * rz + idx, oz = (size_t)b * ZF * rz + idx;
+        const double2 uv = zbuf[oz];
         if (u) { u[o] = uv.x; v[o] = uv.y; }
         const double qv = q[o];
-        zbuf[o] = make_double2((uv.x + d.U[k]) * qv, uv.y * qv);
+        zbuf[oz] = make_double2((uv.x + d.U[k]) * qv, uv.y * qv);
     }
 }
 
@@ -166,7 +169,7 @@ __global__ void k_l_tendency(SpecDev d, StepArgs a, const double2 *zbuf) {
         const double2 q0 = qh0[idx], q1 = qh1[idx];
         const double kx = d.kk[i], ly = d.ll[j];
         for (int k = 0; k < 2; ++k) {
-            const double2 *Z = zbuf + ((size_t)b * 2 + k) * N * N;
+            const double2 *Z = zbuf + ((size_t)b * ZF + k) * N * N;
             const double2 A = Z[(size_t)j * N + i], C = Z[(size_t)jm * N + im];
             const double2 uqh = make_double2(0.5 * (A.x + C.x), 0.5 * (A.y - C.y));
             const double2 vqh = make_double2(0.5 * (A.y + C.y), -0.5 * (A.x - C.x));
@@ -191,10 +194,226 @@ __global__ void k_l_tendency(SpecDev d, StepArgs a, const double2 *zbuf) {
     }
 }
 
+// ================================================================================================
+// Fused step kernels: every pointwise phase rides in the row or column FFT kernel next to it, so one
+// step is 5 launches (7 with a forcing) and ~19 MB of traffic per 256x256 member instead of 18 / ~39.
+// Row kernels own MIRROR PAIRS of rows (j, N-j) [and (0, N/2)]: the Hermitian extension of a packed
+// spectrum needs row -j to build row j, and unpacking row j needs the transformed row -j.
+// ================================================================================================
+__device__ __forceinline__ int pair_row(int p, int which, int N) {      // p in [0, N/2): rows of pair p
+    if (p == 0) return which ? N / 2 : 0;
+    return which ? N - p : p;
+}
+
+// MODE 0: lines = (row, layer k): spectrum of (u_k + i v_k)/N^2 built from qh, inverse FFT along x -> zbuf[b][k]
+// MODE 1: lines = rows of the pair (A,B) = (src[b][0], src[b][1]) -> zbuf[b][2]
+template <int MODE>
+__global__ void k_l_rows_build_inv(SpecDev d, const double2 *src, double2 *zbuf, double2 *ph_out, int PPW) {
+    constexpr int NF = MODE == 0 ? 2 : 1;
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    const int N = d.N, NK = d.NK, LD = N + 1, sz = N * NK;
+    const int nlines = PPW * 2 * NF;
+    int *pos = reinterpret_cast<int *>(L + (size_t)nlines * LD);
+    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    const int groups = (N / 2) / PPW;
+    const int b = blockIdx.x / groups, p0 = (blockIdx.x - b * groups) * PPW;
+    const double2 *s0 = src + (size_t)b * 2 * sz, *s1 = s0 + sz;
+    __syncthreads();
+    for (int t = threadIdx.x; t < PPW * 2 * NK; t += blockDim.x) {
+        const int i = t % NK, r = t / NK;                 // r = local row: pair r>>1, member r&1
+        const int j = pair_row(p0 + (r >> 1), r & 1, N), jm = neg_mod_l(j, N);
+        const int rm = (p0 + (r >> 1)) == 0 ? r : (r ^ 1);   // local row holding row -j
+        const int idx = j * NK + i, idm = jm * NK + i;
+        const bool selfc = (i == 0 || 2 * i == N);
+        const double2 q0 = s0[idx], q1 = s1[idx];
+        double2 q0m = q0, q1m = q1;
+        if (selfc) { q0m = s0[idm]; q1m = s1[idm]; }
+        if constexpr (MODE == 0) {
+            const double kx = d.kk[i], ly = d.ll[j], lm = d.ll[jm];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double2 ph = invert_l(d, k, idx, q0, q1);
+                if (ph_out) ph_out[(size_t)b * 2 * sz + k * sz + idx] = ph;
+                double2 uh = make_double2(ly * ph.y, -ly * ph.x);
+                double2 vh = make_double2(-kx * ph.y, kx * ph.x);
+                if (selfc) {
+                    const double2 pm = invert_l(d, k, idm, q0m, q1m);
+                    const double2 um = make_double2(lm * pm.y, -lm * pm.x);
+                    const double2 vm = make_double2(-kx * pm.y, kx * pm.x);
+                    uh = make_double2(0.5 * (uh.x + um.x), 0.5 * (uh.y - um.y));
+                    vh = make_double2(0.5 * (vh.x + vm.x), 0.5 * (vh.y - vm.y));
+                }
+                L[(r * NF + k) * LD + pos[i]] = make_double2((uh.x - vh.y) * d.invN2, (uh.y + vh.x) * d.invN2);
+                if (!selfc) L[(rm * NF + k) * LD + pos[N - i]] = make_double2((uh.x + vh.y) * d.invN2, (vh.x - uh.y) * d.invN2);
+            }
+        } else {
+            double2 a = q0, bb = q1;
+            if (selfc) {
+                a = make_double2(0.5 * (a.x + q0m.x), 0.5 * (a.y - q0m.y));
+                bb = make_double2(0.5 * (bb.x + q1m.x), 0.5 * (bb.y - q1m.y));
+            }
+            L[r * LD + pos[i]] = make_double2((a.x - bb.y) * d.invN2, (a.y + bb.x) * d.invN2);
+            if (!selfc) L[rm * LD + pos[N - i]] = make_double2((a.x + bb.y) * d.invN2, (bb.x - a.y) * d.invN2);
+        }
+    }
+    __syncthreads();
+    fft_lines_inv(L, nlines, LD, 1, N, d.nrad, d.rad, d.tw);
+    for (int t = threadIdx.x; t < nlines * N; t += blockDim.x) {
+        const int e = t % N, line = t / N;
+        const int r = line / NF, k = line - r * NF;
+        const int j = pair_row(p0 + (r >> 1), r & 1, N);
+        zbuf[((size_t)b * ZF + (MODE == 0 ? k : 2)) * N * N + (size_t)j * N + e] = L[line * LD + e];
+    }
+}
+
+// rows of (w*S_1 + i w*S_2) -> forward FFT along x -> zbuf[b][2]
+__global__ void k_l_rows_S(SpecDev d, const double *S, double2 *zbuf, double w, int LPB) {
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    const int N = d.N, LD = N + 1, rz = N * N;
+    int *pos = reinterpret_cast<int *>(L + (size_t)LPB * LD);
+    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    const int groups = N / LPB;
+    const int b = blockIdx.x / groups, j0 = (blockIdx.x - b * groups) * LPB;
+    const double *S0 = S + (size_t)b * 2 * rz, *S1 = S0 + rz;
+    for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
+        const int e = t % N, l = t / N;
+        const size_t o = (size_t)(j0 + l) * N + e;
+        L[l * LD + e] = make_double2(w * S0[o], w * S1[o]);
+    }
+    __syncthreads();
+    fft_lines_fwd(L, LPB, LD, 1, N, d.nrad, d.rad, d.tw);
+    double2 *g = zbuf + ((size_t)b * ZF + 2) * N * N;
+    for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
+        const int e = t % N, l = t / N;
+        g[(size_t)(j0 + l) * N + e] = L[l * LD + pos[e]];
+    }
+}
+
+// column tiles.  MODE 0: zbuf[b][k]: inverse along y, (u,v) -> ((u+U_k) q, v q), forward along y
+//                MODE 1: zbuf[b][2]: forward along y (forcing pair)
+//                MODE 2: zbuf[b][2]: inverse along y, real/imag parts -> q_1, q_2
+template <int MODE>
+__global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double *v, int CPB) {
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    const int N = d.N, LD = N + 1, rz = N * N;
+    int *pos = reinterpret_cast<int *>(L + (size_t)CPB * LD);
+    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    const int groups = N / CPB;
+    const int nf = MODE == 0 ? 2 : 1;
+    const int f = blockIdx.x / groups, c0 = (blockIdx.x - f * groups) * CPB;
+    const int b = f / nf, k = MODE == 0 ? f - b * nf : 2;
+    double2 *g = zbuf + ((size_t)b * ZF + k) * N * N;
+    __syncthreads();
+    for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
+        const int r = t / CPB, c = t - r * CPB;
+        L[c * LD + (MODE == 1 ? r : pos[r])] = g[(size_t)r * N + c0 + c];
+    }
+    __syncthreads();
+    if constexpr (MODE == 1) {
+        fft_lines_fwd(L, CPB, LD, 1, N, d.nrad, d.rad, d.tw);
+    } else {
+        fft_lines_inv(L, CPB, LD, 1, N, d.nrad, d.rad, d.tw);
+    }
+    if constexpr (MODE == 0) {
+        const double Uk = d.U[k];
+        const size_t ro = (size_t)b * 2 * rz + (size_t)k * rz;
+        for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
+            const int r = t / CPB, c = t - r * CPB;
+            const double2 uv = L[c * LD + r];
+            const size_t o = ro + (size_t)r * N + c0 + c;
+            if (u) { u[o] = uv.x; v[o] = uv.y; }
+            const double qv = q[o];
+            L[c * LD + r] = make_double2((uv.x + Uk) * qv, uv.y * qv);
+        }
+        __syncthreads();
+        fft_lines_fwd(L, CPB, LD, 1, N, d.nrad, d.rad, d.tw);
+    }
+    if constexpr (MODE == 2) {
+        double *q0 = q + (size_t)b * 2 * rz, *q1 = q0 + rz;
+        for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
+            const int r = t / CPB, c = t - r * CPB;
+            const double2 w = L[c * LD + r];
+            q0[(size_t)r * N + c0 + c] = w.x;
+            q1[(size_t)r * N + c0 + c] = w.y;
+        }
+    } else {
+        for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
+            const int r = t / CPB, c = t - r * CPB;
+            g[(size_t)r * N + c0 + c] = L[c * LD + pos[r]];
+        }
+    }
+}
+
+// rows of zbuf[b][0..1] (pairs j, -j): forward FFT along x, unpack (uq_k, vq_k), tendency + friction + forcing,
+// AB3 + filter -> dq_new, qh_out.  The forcing spectrum is read from zbuf[b][2] (already transformed).
+__global__ void k_l_rows_fwd_tend(SpecDev d, StepArgs a, const double2 *zbuf, int PPW) {
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    const int N = d.N, NK = d.NK, LD = N + 1, sz = N * NK;
+    const int nlines = PPW * 4;
+    int *pos = reinterpret_cast<int *>(L + (size_t)nlines * LD);
+    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    const int groups = (N / 2) / PPW;
+    const int b = blockIdx.x / groups, p0 = (blockIdx.x - b * groups) * PPW;
+    for (int t = threadIdx.x; t < nlines * N; t += blockDim.x) {
+        const int e = t % N, line = t / N;
+        const int r = line >> 1, k = line & 1;
+        const int j = pair_row(p0 + (r >> 1), r & 1, N);
+        L[line * LD + e] = zbuf[((size_t)b * ZF + k) * N * N + (size_t)j * N + e];
+    }
+    __syncthreads();
+    fft_lines_fwd(L, nlines, LD, 1, N, d.nrad, d.rad, d.tw);
+    const double2 *qh0 = a.qh_in + (size_t)b * 2 * sz, *qh1 = qh0 + sz;
+    const double2 *ZS = zbuf + ((size_t)b * ZF + 2) * N * N;
+    for (int t = threadIdx.x; t < PPW * 2 * NK; t += blockDim.x) {
+        const int i = t % NK, r = t / NK;
+        const int j = pair_row(p0 + (r >> 1), r & 1, N), jm = neg_mod_l(j, N), im = neg_mod_l(i, N);
+        const int rm = (p0 + (r >> 1)) == 0 ? r : (r ^ 1);
+        const int idx = j * NK + i;
+        const double2 q0 = qh0[idx], q1 = qh1[idx];
+        const double kx = d.kk[i], ly = d.ll[j];
+        double2 s0 = make_double2(0., 0.), s1 = s0;
+        if (a.has_S) {
+            const double2 A = ZS[(size_t)j * N + i], C = ZS[(size_t)jm * N + im];
+            s0 = make_double2(0.5 * (A.x + C.x), 0.5 * (A.y - C.y));
+            s1 = make_double2(0.5 * (A.y + C.y), -0.5 * (A.x - C.x));
+            if (a.demean && idx == 0) { s0 = make_double2(0., 0.); s1 = s0; }
+            if (a.diag) { a.dqh[(size_t)b * 2 * sz + idx] = s0; a.dqh[(size_t)b * 2 * sz + sz + idx] = s1; }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double2 A = L[(r * 2 + k) * LD + pos[i]], C = L[(rm * 2 + k) * LD + pos[im]];
+            const double2 uqh = make_double2(0.5 * (A.x + C.x), 0.5 * (A.y - C.y));
+            const double2 vqh = make_double2(0.5 * (A.y + C.y), -0.5 * (A.x - C.x));
+            const double2 ph = invert_l(d, k, idx, q0, q1);
+            const double kq = kx * d.Qy[k];
+            double tx = (kx * uqh.y + ly * vqh.y + kq * ph.y);
+            double ty = -(kx * uqh.x + ly * vqh.x + kq * ph.x);
+            if (k == 1 && d.rek != 0.0) {
+                const double f = d.rek * d.wv2[idx];
+                tx += f * ph.x;
+                ty += f * ph.y;
+            }
+            const double2 s = k == 0 ? s0 : s1;
+            tx += s.x; ty += s.y;
+            const size_t o = (size_t)b * 2 * sz + k * sz + idx;
+            const double2 p = a.dq_p[o], pp = a.dq_pp[o];
+            const double2 qk = k == 0 ? q0 : q1;
+            const double f = d.filtr[idx];
+            a.dq_new[o] = make_double2(tx, ty);
+            a.qh_out[o] = make_double2(f * (qk.x + a.dt1 * tx + a.dt2 * p.x + a.dt3 * pp.x),
+                                       f * (qk.y + a.dt1 * ty + a.dt2 * p.y + a.dt3 * pp.y));
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 static int lines_per_block(int N) {
+    static const int forced = getenv("QGX_LARGE_LPB") ? atoi(getenv("QGX_LARGE_LPB")) : 0;   // tuning aid
+    if (forced > 0 && N % forced == 0) return forced;
     int lpb = 64;
-    while (lpb > 1 && ((size_t)lpb * (N + 1) * 16 + (size_t)N * 4 > 72 * 1024 || N % lpb)) lpb /= 2;
+    // <= 36 KB of LDS per workgroup: 4 workgroups per CU hide the global-memory latency of these
+    // short kernels better than longer lines do (256x256, B=64: 360 us/step at 8 lines vs 456 at 16)
+    while (lpb > 1 && ((size_t)lpb * (N + 1) * 16 + (size_t)N * 4 > 36 * 1024 || N % lpb)) lpb /= 2;
     return lpb;
 }
 static size_t lines_lds(int N, int lpb) { return (((size_t)lpb * (N + 1) * 16 + (size_t)N * 4) + 15) & ~(size_t)15; }
@@ -205,21 +424,25 @@ int large_prepare(const SpecDev &d) {
     QGX_HIP(hipFuncSetAttribute((const void *)k_lines_fft<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QGX_HIP(hipFuncSetAttribute((const void *)k_lines_fft<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     QGX_HIP(hipFuncSetAttribute((const void *)k_lines_fft<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    const void *fused[] = {(const void *)k_l_rows_build_inv<0>, (const void *)k_l_rows_build_inv<1>, (const void *)k_l_rows_S,
+                           (const void *)k_l_cols<0>, (const void *)k_l_cols<1>, (const void *)k_l_cols<2>,
+                           (const void *)k_l_rows_fwd_tend};
+    for (const void *f : fused) QGX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     return QGX_OK;
 }
 
-// 2-D FFT of nf fields starting at base with stride fstride
+// 2-D FFT of the work fields [k0, k0+nfpm) of every member
 template <bool FWD>
-static int fft2d_large(const SpecDev &d, double2 *base, size_t fstride, int nf, hipStream_t st) {
+static int fft2d_large(const SpecDev &d, double2 *base, int k0, int nfpm, hipStream_t st) {
     const int lpb = lines_per_block(d.N);
     const size_t lds = lines_lds(d.N, lpb);
-    dim3 grid(nf * (d.N / lpb)), block(256);
+    dim3 grid(d.B * nfpm * (d.N / lpb)), block(256);
     if (FWD) {
-        hipLaunchKernelGGL((k_lines_fft<true, false>), grid, block, lds, st, d, base, fstride, lpb);
-        hipLaunchKernelGGL((k_lines_fft<true, true>), grid, block, lds, st, d, base, fstride, lpb);
+        hipLaunchKernelGGL((k_lines_fft<true, false>), grid, block, lds, st, d, base, k0, nfpm, lpb);
+        hipLaunchKernelGGL((k_lines_fft<true, true>), grid, block, lds, st, d, base, k0, nfpm, lpb);
     } else {
-        hipLaunchKernelGGL((k_lines_fft<false, true>), grid, block, lds, st, d, base, fstride, lpb);
-        hipLaunchKernelGGL((k_lines_fft<false, false>), grid, block, lds, st, d, base, fstride, lpb);
+        hipLaunchKernelGGL((k_lines_fft<false, true>), grid, block, lds, st, d, base, k0, nfpm, lpb);
+        hipLaunchKernelGGL((k_lines_fft<false, false>), grid, block, lds, st, d, base, k0, nfpm, lpb);
     }
     QGX_HIP(hipGetLastError());
     return QGX_OK;
@@ -229,9 +452,8 @@ static dim3 pw_grid(const SpecDev &d, int n) { return dim3((unsigned)((n + 255) 
 
 int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st) {
     const SpecDev &d = m->d;
-    const size_t f2 = (size_t)2 * d.N * d.N;
     hipLaunchKernelGGL(k_l_pack_real, pw_grid(d, d.N * d.N), dim3(256), 0, st, d, q, m->zbuf, 1.0);
-    int rc = fft2d_large<true>(d, m->zbuf, f2, d.B, st);
+    int rc = fft2d_large<true>(d, m->zbuf, 0, 1, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_l_unpack_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->zbuf, qh, 0);
     QGX_HIP(hipGetLastError());
@@ -240,9 +462,8 @@ int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st) {
 
 int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st) {
     const SpecDev &d = m->d;
-    const size_t f2 = (size_t)2 * d.N * d.N;
     hipLaunchKernelGGL(k_l_build_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, qh, m->zbuf);
-    int rc = fft2d_large<false>(d, m->zbuf, f2, d.B, st);
+    int rc = fft2d_large<false>(d, m->zbuf, 0, 1, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_l_unpack_real, pw_grid(d, d.N * d.N), dim3(256), 0, st, d, m->zbuf, q);
     QGX_HIP(hipGetLastError());
@@ -251,9 +472,8 @@ int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st) {
 
 int large_invert(qgx_model *m, hipStream_t st) {
     const SpecDev &d = m->d;
-    const size_t f1 = (size_t)d.N * d.N;
     hipLaunchKernelGGL(k_l_build_uv, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->qh[m->cur_q], m->zbuf, m->ph);
-    int rc = fft2d_large<false>(d, m->zbuf, f1, 2 * d.B, st);
+    int rc = fft2d_large<false>(d, m->zbuf, 0, 2, st);
     if (rc) return rc;
     // the product kernel doubles as the (u, v) unpacker; what it leaves in the scratch zbuf is unused
     hipLaunchKernelGGL(k_l_products, pw_grid(d, 2 * d.N * d.N), dim3(256), 0, st, d, m->zbuf, m->q, m->u, m->v);
@@ -261,25 +481,50 @@ int large_invert(qgx_model *m, hipStream_t st) {
     return QGX_OK;
 }
 
-int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
+static int large_step_unfused(qgx_model *m, const StepArgs &a, hipStream_t st) {
     const SpecDev &d = m->d;
-    const size_t f1 = (size_t)d.N * d.N, f2 = 2 * f1;
     int rc;
     if (a.has_S) {
         hipLaunchKernelGGL(k_l_pack_real, pw_grid(d, d.N * d.N), dim3(256), 0, st, d, a.S, m->zbuf, a.weight);
-        if ((rc = fft2d_large<true>(d, m->zbuf, f2, d.B, st))) return rc;
+        if ((rc = fft2d_large<true>(d, m->zbuf, 0, 1, st))) return rc;
         hipLaunchKernelGGL(k_l_unpack_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->zbuf, a.dqh, a.demean);
     }
     hipLaunchKernelGGL(k_l_build_uv, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, a.qh_in, m->zbuf,
                        a.diag ? a.ph : (double2 *)nullptr);
-    if ((rc = fft2d_large<false>(d, m->zbuf, f1, 2 * d.B, st))) return rc;
+    if ((rc = fft2d_large<false>(d, m->zbuf, 0, 2, st))) return rc;
     hipLaunchKernelGGL(k_l_products, pw_grid(d, 2 * d.N * d.N), dim3(256), 0, st, d, m->zbuf, a.q,
                        a.diag ? a.u : (double *)nullptr, a.diag ? a.v : (double *)nullptr);
-    if ((rc = fft2d_large<true>(d, m->zbuf, f1, 2 * d.B, st))) return rc;
+    if ((rc = fft2d_large<true>(d, m->zbuf, 0, 2, st))) return rc;
     hipLaunchKernelGGL(k_l_tendency, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, a, (const double2 *)m->zbuf);
     hipLaunchKernelGGL(k_l_build_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, (const double2 *)a.qh_out, m->zbuf);
-    if ((rc = fft2d_large<false>(d, m->zbuf, f2, d.B, st))) return rc;
+    if ((rc = fft2d_large<false>(d, m->zbuf, 0, 1, st))) return rc;
     hipLaunchKernelGGL(k_l_unpack_real, pw_grid(d, d.N * d.N), dim3(256), 0, st, d, m->zbuf, a.q);
+    QGX_HIP(hipGetLastError());
+    return QGX_OK;
+}
+
+int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
+    static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+    const SpecDev &d = m->d;
+    const int lpb = lines_per_block(d.N);
+    if (unfused || lpb < 4 || (d.N / 2) % (lpb / 4)) return large_step_unfused(m, a, st);
+    const size_t lds = lines_lds(d.N, lpb);
+    const int B = d.B, N = d.N;
+    if (a.has_S) {
+        hipLaunchKernelGGL(k_l_rows_S, dim3(B * (N / lpb)), dim3(256), lds, st, d, a.S, m->zbuf, a.weight, lpb);
+        hipLaunchKernelGGL(k_l_cols<1>, dim3(B * (N / lpb)), dim3(256), lds, st, d, m->zbuf, (double *)nullptr,
+                           (double *)nullptr, (double *)nullptr, lpb);
+    }
+    hipLaunchKernelGGL(k_l_rows_build_inv<0>, dim3(B * ((N / 2) / (lpb / 4))), dim3(256), lds, st, d, a.qh_in, m->zbuf,
+                       a.diag ? a.ph : (double2 *)nullptr, lpb / 4);
+    hipLaunchKernelGGL(k_l_cols<0>, dim3(B * 2 * (N / lpb)), dim3(256), lds, st, d, m->zbuf, a.q,
+                       a.diag ? a.u : (double *)nullptr, a.diag ? a.v : (double *)nullptr, lpb);
+    hipLaunchKernelGGL(k_l_rows_fwd_tend, dim3(B * ((N / 2) / (lpb / 4))), dim3(256), lds, st, d, a,
+                       (const double2 *)m->zbuf, lpb / 4);
+    hipLaunchKernelGGL(k_l_rows_build_inv<1>, dim3(B * ((N / 2) / (lpb / 2))), dim3(256), lds, st, d,
+                       (const double2 *)a.qh_out, m->zbuf, (double2 *)nullptr, lpb / 2);
+    hipLaunchKernelGGL(k_l_cols<2>, dim3(B * (N / lpb)), dim3(256), lds, st, d, m->zbuf, a.q, (double *)nullptr,
+                       (double *)nullptr, lpb);
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }

@@ -132,9 +132,10 @@ def test_many_steps_in_one_call_equals_single_steps():
     assert torch.equal(e1.get(L.F_QH), e2.get(L.F_QH))       # deterministic: bit-identical
 
 
-def test_external_forcing_matches_oracle_q_parameterization():
+@pytest.mark.parametrize('N', [64, 128, 256])
+def test_external_forcing_matches_oracle_q_parameterization(N):
     import pyqg_generative_amd._lib as L
-    N, B = 64, 2
+    B = 2
     rs = np.random.RandomState(9)
     q0 = _eddy_like_q(rs, B, N)
     Ss = [rs.randn(B, 2, N, N) * np.array([7e-12, 2e-13])[None, :, None, None] for _ in range(4)]
