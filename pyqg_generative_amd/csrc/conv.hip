@@ -528,7 +528,7 @@ struct LastWeights { float w[3 * 3 * 32 * 2]; };   // [tap][c][2], passed BY VAL
 
 template <int CIN, int KS>
 __global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
-    constexpr int P = KS / 2, T = KS * KS, STRIDE = CIN + 4, C4 = CIN / 4;
+    constexpr int P = KS / 2, STRIDE = CIN + 4, C4 = CIN / 4;
     float *patch = reinterpret_cast<float *>(conv_smem);
     const int N = a.N, R = a.R;
     const int tiles_per_img = N / R;
