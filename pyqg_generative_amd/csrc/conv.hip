@@ -891,9 +891,10 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
     done = false;
     constexpr int T = KS * KS, NSL = T / TPS, NTc = (COUT + 31) / 32;
     constexpr size_t WSLB = (size_t)TPS * (CC / 8) * 2 * NTc * 32 * 4 * sizeof(float);
-    // rows per tile: as k_conv (8 or 12 M-tiles), LDS = 2 patches + 2 weight slices
-    const int R = choose_rows(N);
+    // rows per tile: as k_conv (8 or 12 M-tiles; twice that with 8 waves), LDS = 2 patches + 2 weight slices
+    int R = choose_rows(N);
     if (R == 0 || N % R) return QGX_OK;
+    if (NW == 8) { if (N % (2 * R)) return QGX_OK; R *= 2; }
     const int ntiles = R * N / 32;
     const int PR = R + KS - 1;
     const size_t lds = (size_t)2 * PR * N * (CC + 4) * sizeof(float) + 2 * WSLB;
@@ -930,19 +931,28 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
 }
 
 // hidden layers: k_conv3 (LDS-only operands, prefetched staging) where it measured faster (CIN <= 64 at
-// 64x64: -8..-10 %; the 128->64 5x5 layer ties), else the one-shot k_conv.  "v3" option: -1 auto, 0 off,
-// 1 = weight slice per tap row, 2 = per chunk.
+// 64x64: -8..-13 %; the 128->64 5x5 layer ties), else the one-shot k_conv.  "v3" option: -1 auto, 0 off,
+// 1 = 4 waves, weight slice per tap row; 2 = 4 waves, slice per chunk; 6 / 7 = the same with 8 waves and
+// double-height tiles.  Auto: 8 waves (slice per tap row for CIN = 32, per chunk for CIN = 64), falling
+// back to 4 waves and then to k_conv when the LDS budget does not fit.
 template <int CIN, int COUT, int KS>
 static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                        int N, hipStream_t st) {
     if (g->opt_small && small_ensemble(B, N)) return launch_conv_small<CIN, COUT, KS>(g, layer, L, in, out, B, N, st);
-    const int v3 = g->opt_v3 >= 0 ? g->opt_v3 : (CIN <= 64 ? 1 : 0);
-    if (v3) {
-        bool done;
-        int rc = v3 == 2 ? launch_conv3<CIN, COUT, KS, KS * KS>(g, layer, L, in, out, B, N, st, done)
-                         : launch_conv3<CIN, COUT, KS, KS>(g, layer, L, in, out, B, N, st, done);
-        if (rc || done) return rc;
-    }
+    bool done = false;
+    int rc = QGX_OK;
+    const int v3 = g->opt_v3;
+    if (v3 < 0) {
+        if (CIN <= 64) {
+            rc = CIN == 64 ? launch_conv3<CIN, COUT, KS, KS * KS, 16, 8>(g, layer, L, in, out, B, N, st, done)
+                           : launch_conv3<CIN, COUT, KS, KS, 16, 8>(g, layer, L, in, out, B, N, st, done);
+            if (!rc && !done) rc = launch_conv3<CIN, COUT, KS, KS>(g, layer, L, in, out, B, N, st, done);
+        }
+    } else if (v3 == 1) rc = launch_conv3<CIN, COUT, KS, KS>(g, layer, L, in, out, B, N, st, done);
+    else if (v3 == 2) rc = launch_conv3<CIN, COUT, KS, KS * KS>(g, layer, L, in, out, B, N, st, done);
+    else if (v3 == 6) rc = launch_conv3<CIN, COUT, KS, KS, 16, 8>(g, layer, L, in, out, B, N, st, done);
+    else if (v3 == 7) rc = launch_conv3<CIN, COUT, KS, KS * KS, 16, 8>(g, layer, L, in, out, B, N, st, done);
+    if (rc || done) return rc;
     if (g->opt_cc == 32) return launch_conv<CIN, COUT, KS, 32, false, false>(g, layer, L, in, out, B, N, COUT, st);
     return launch_conv<CIN, COUT, KS, 16, false, false>(g, layer, L, in, out, B, N, COUT, st);
 }
