@@ -7,8 +7,8 @@
 // executed as six complex N x N transforms of packed pairs
 //   (u_k + i v_k), ((u_k+U_k) q_k + i v_k q_k), (S_1 + i S_2), (q_1 + i q_2)
 // entirely inside one CU's LDS (N <= 96: N*(N+1)*16 B <= 149 KB).
-#include "common.hpp"
-#include "fft_lds.hpp"
+#include "../pyqg_generative_amd/csrc/common.hpp"
+#include "../pyqg_generative_amd/csrc/fft_lds.hpp"
 #include <cstdlib>
 
 namespace qgx {
@@ -107,13 +107,14 @@ __device__ __forceinline__ Grid make_grid(const SpecDev &d, double2 *Z, int *&po
 extern __shared__ __attribute__((aligned(16))) char qgx_smem[];
 
 // ------------------------------------------------------------------ one time step
-template <int NN>
-__global__ void k_step_small(SpecDev d, StepArgs a) {
+__global__ void k_step_small_stamped(SpecDev d, StepArgs a, unsigned long long *stamps) {
+    int sidx = 0;
+#define STAMP() do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) stamps[sidx] = __builtin_amdgcn_s_memrealtime(); ++sidx; } while (0)
+    STAMP();
     double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
     int *pos_lds;
     Grid g = make_grid(d, Z, pos_lds);
-    if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
-    const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD;
+    const int N = d.N, NK = d.NK, LD = d.LD;
     const int b = blockIdx.x;
     const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
     const int sz = N * NK, rz = N * N;
@@ -128,7 +129,9 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
             Z[y * LD + x] = make_double2(a.weight * S0[idx], a.weight * S1[idx]);
         }
         __syncthreads();
-        fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+        STAMP();  /* S loaded */
+        fft2d_fwd(Z, N, LD, g.nrad, g.rad, g.tw);
+        STAMP();  /* S fft */
         for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
             const int j = idx / NK, i = idx - j * NK;
             double2 s0, s1;
@@ -142,9 +145,11 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
 
     for (int k = 0; k < 2; ++k) {
         // ---- _invert: ph_k, (u_k, v_k) = irfft2(-il ph, ik ph)
+        STAMP();  /* before build_uv */
         build_uv(Z, g, d, k, qh0, qh1, a.diag ? a.ph + so + k * sz : nullptr);
-        __syncthreads();
-        fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+        STAMP();  /* build_uv */
+        fft2d_inv(Z, N, LD, g.nrad, g.rad, g.tw);
+        STAMP();  /* inv fft */
         // ---- _do_advection, real space: uq = (u+U) q, vq = v q
         {
             const double *qk = a.q + ro + k * rz;
@@ -157,8 +162,9 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
                 Z[y * LD + x] = make_double2((uv.x + Uk) * qv, uv.y * qv);
             }
         }
-        __syncthreads();
-        fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+        STAMP();  /* products */
+        fft2d_fwd(Z, N, LD, g.nrad, g.rad, g.tw);
+        STAMP();  /* fwd fft */
         // ---- spectral tendency, friction, forcing, AB3 + filter (_forward_timestep)
         for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
             const int j = idx / NK, i = idx - j * NK;
@@ -191,151 +197,54 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
         }
         __syncthreads();
     }
+    STAMP();  /* tendency (last layer) */
     // ---- q^{n+1} = irfft2(qh^{n+1}), both layers packed
     build_pair(Z, g, a.qh_out + so, a.qh_out + so + sz, d.invN2);
-    __syncthreads();
-    fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    STAMP();  /* build_pair */
+    fft2d_inv(Z, N, LD, g.nrad, g.rad, g.tw);
+    STAMP();  /* q inv fft */
     for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
         const int y = idx / N, x = idx - y * N;
         const double2 w = Z[y * LD + x];
         a.q[ro + idx] = w.x;
         a.q[ro + rz + idx] = w.y;
     }
+    STAMP();  /* q store */
+#undef STAMP
 }
-
-// ------------------------------------------------------------------ q -> qh (property q setter)
-template <int NN>
-__global__ void k_q_to_qh_small(SpecDev d, const double *q, double2 *qh) {
-    double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
-    int *pos_lds;
-    Grid g = make_grid(d, Z, pos_lds);
-    if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
-    const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD, b = blockIdx.x;
-    const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
-    const int sz = N * NK, rz = N * N;
-    for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
-        const int y = idx / N, x = idx - y * N;
-        Z[y * LD + x] = make_double2(q[ro + idx], q[ro + rz + idx]);
-    }
-    __syncthreads();
-    fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
-    for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
-        const int j = idx / NK, i = idx - j * NK;
-        double2 s0, s1;
-        unpack_pair(Z, g, j, i, s0, s1);
-        qh[so + idx] = s0;
-        qh[so + sz + idx] = s1;
-    }
-}
-
-// ------------------------------------------------------------------ qh -> q
-template <int NN>
-__global__ void k_qh_to_q_small(SpecDev d, const double2 *qh, double *q) {
-    double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
-    int *pos_lds;
-    Grid g = make_grid(d, Z, pos_lds);
-    if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
-    const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD, b = blockIdx.x;
-    const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
-    const int sz = N * NK, rz = N * N;
-    __syncthreads();
-    build_pair(Z, g, qh + so, qh + so + sz, d.invN2);
-    __syncthreads();
-    fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
-    for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
-        const int y = idx / N, x = idx - y * N;
-        const double2 w = Z[y * LD + x];
-        q[ro + idx] = w.x;
-        q[ro + rz + idx] = w.y;
-    }
-}
-
-// ------------------------------------------------------------------ _invert only
-template <int NN>
-__global__ void k_invert_small(SpecDev d, const double2 *qh, double2 *ph, double *u, double *v) {
-    double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
-    int *pos_lds;
-    Grid g = make_grid(d, Z, pos_lds);
-    if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
-    const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD, b = blockIdx.x;
-    const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
-    const int sz = N * NK, rz = N * N;
-    __syncthreads();
-    for (int k = 0; k < 2; ++k) {
-        build_uv(Z, g, d, k, qh + so, qh + so + sz, ph + so + k * sz);
-        __syncthreads();
-        fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
-        for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
-            const int y = idx / N, x = idx - y * N;
-            const double2 uv = Z[y * LD + x];
-            u[ro + k * rz + idx] = uv.x;
-            v[ro + k * rz + idx] = uv.y;
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------ host launchers
-static size_t small_lds_bytes(const SpecDev &d) {
-    size_t bytes = (size_t)d.N * d.LD * sizeof(double2) + (size_t)d.N * sizeof(int);
-    return (bytes + 15) & ~(size_t)15;
-}
-static int small_threads(const SpecDev &d) {
-    static const int forced = getenv("QGX_SPEC_THREADS") ? atoi(getenv("QGX_SPEC_THREADS")) : 0;   // tuning aid
-    if (forced > 0) return forced;
-    // One workgroup advances one member.  With at most one member per CU the kernel is a latency chain
-    // (about 50 barriers): 1024 threads shorten it (B=128, N=64: 119 -> 71 us); with several members
-    // queued per CU 512 threads give the best throughput (B=1024: 293 us vs 385 @256 / 337 @1024).
-    // Grids above 64x64 leave room for one workgroup per CU only: always 1024 threads there.
-    return (d.B <= 256 || d.N > 64) ? 1024 : 512;
-}
-
-bool small_path_fits(int N) {
-    return (size_t)N * (N + 1) * 16 + (size_t)N * 4 + 16 <= 160 * 1024;
-}
-
-// kernels specialised for the grid sizes the reference runs (compile-time index arithmetic and FFT
-// plan), generic run-time-N kernels for every other 2^a 3^b size
-#define QGX_DISPATCH_N(N_, CALL)                \
-    switch (N_) {                               \
-        case 32: { constexpr int NN = 32; CALL; } break; \
-        case 48: { constexpr int NN = 48; CALL; } break; \
-        case 64: { constexpr int NN = 64; CALL; } break; \
-        case 96: { constexpr int NN = 96; CALL; } break; \
-        default: { constexpr int NN = 0; CALL; } break;  \
-    }
-
-int small_prepare(const SpecDev &d) {
-    const int bytes = (int)small_lds_bytes(d);
-    QGX_DISPATCH_N(d.N, {
-        QGX_HIP(hipFuncSetAttribute((const void *)k_step_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        QGX_HIP(hipFuncSetAttribute((const void *)k_q_to_qh_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        QGX_HIP(hipFuncSetAttribute((const void *)k_qh_to_q_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    })
-    return QGX_OK;
-}
-
-int small_step(const SpecDev &d, const StepArgs &a, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_step_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, a))
-    QGX_HIP(hipGetLastError());
-    return QGX_OK;
-}
-int small_q_to_qh(const SpecDev &d, const double *q, double2 *qh, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_q_to_qh_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, q, qh))
-    QGX_HIP(hipGetLastError());
-    return QGX_OK;
-}
-int small_qh_to_q(const SpecDev &d, const double2 *qh, double *q, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_qh_to_q_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, qh, q))
-    QGX_HIP(hipGetLastError());
-    return QGX_OK;
-}
-int small_invert(const SpecDev &d, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_invert_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, qh, ph, u, v))
-    QGX_HIP(hipGetLastError());
-    return QGX_OK;
-}
-#undef QGX_DISPATCH_N
 
 }  // namespace qgx
+
+// Diagnostic build ONLY (never timed as a whole): phase shares of one workgroup of the spectral step.
+#include <vector>
+#include <cmath>
+using namespace qgx;
+int main(int argc, char **argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 1, N = 64, NK = 33, T = argc > 2 ? atoi(argv[2]) : 1024;
+    qgx_config cfg = {N, B, 0, 0, 1e6, 14400., 5.787e-7, 0.25, 1.5e-11, 15000., 0.025, 0., 500., 23.6};
+    qgx_model *m;
+    if (qgx_create(&cfg, &m)) { printf("create failed: %s\n", qgx_last_error()); return 1; }
+    std::vector<double> q((size_t)B * 2 * N * N);
+    for (size_t i = 0; i < q.size(); ++i) q[i] = 1e-6 * sin(0.37 * i);
+    double *qd; hipMalloc(&qd, q.size() * 8); hipMemcpy(qd, q.data(), q.size() * 8, hipMemcpyHostToDevice);
+    qgx_set_q(m, qd, 0);
+    qgx_step(m, 3, nullptr, 0, 0);
+    unsigned long long *st; hipMalloc(&st, 64 * 8); hipMemset(st, 0, 64 * 8);
+    StepArgs a; a.qh_in = m->qh[m->cur_q]; a.qh_out = m->qh[m->cur_q ^ 1]; a.q = m->q; a.S = m->S; a.dqh = m->dqh;
+    a.dq_new = m->dq[m->i_pp]; a.dq_p = m->dq[m->i_new]; a.dq_pp = m->dq[m->i_p]; a.ph = m->ph; a.u = m->u; a.v = m->v;
+    a.dt1 = 1.9 * 14400; a.dt2 = -1.3 * 14400; a.dt3 = 0.4 * 14400; a.weight = 1; a.has_S = 1; a.demean = 1; a.diag = 0;
+    const size_t lds = (size_t)N * (N + 1) * 16 + N * 4 + 16;
+    hipFuncSetAttribute((const void *)k_step_small_stamped, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(k_step_small_stamped, dim3(B), dim3(T), lds, 0, m->d, a, st);
+        hipDeviceSynchronize();
+    }
+    unsigned long long h[64]; hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost);
+    const char *names[] = {"S load", "S fwd fft", "S unpack+L0 pre", "L0 build_uv", "L0 inv fft", "L0 products", "L0 fwd fft",
+                           "L0 tendency", "L1 build_uv", "L1 inv fft", "L1 products", "L1 fwd fft", "L1 tendency", "build_pair",
+                           "q inv fft", "q store"};
+    printf("B=%d threads=%d (100 MHz ticks -> us)\n", B, T);
+    for (int i = 1; i < 17 && h[i]; ++i) printf("  %-18s %6.2f us\n", names[i - 1], (h[i] - h[i - 1]) / 100.0);
+    printf("  total %.2f us\n", (h[16] - h[0]) / 100.0);
+    return 0;
+}

@@ -97,13 +97,18 @@ __device__ __forceinline__ void fft_pass(double2 *Z, int nl, int ls, int es, int
         double2 v[R];
 #pragma unroll
         for (int m = 0; m < R; ++m) v[m] = base[m * step];
+        // (when the block is one butterfly, sub == 1, every twiddle is 1: skip loads and multiplies)
         if constexpr (FWD) {
             small_dft<R, true>(v);
+            if (sub > 1) {
 #pragma unroll
-            for (int m = 1; m < R; ++m) v[m] = cmul(v[m], tw[m * b * tstride]);
+                for (int m = 1; m < R; ++m) v[m] = cmul(v[m], tw[m * b * tstride]);
+            }
         } else {
+            if (sub > 1) {
 #pragma unroll
-            for (int m = 1; m < R; ++m) v[m] = cmulc(v[m], tw[m * b * tstride]);
+                for (int m = 1; m < R; ++m) v[m] = cmulc(v[m], tw[m * b * tstride]);
+            }
             small_dft<R, false>(v);
         }
 #pragma unroll
@@ -137,6 +142,50 @@ __device__ __forceinline__ void fft_lines_inv(double2 *Z, int nl, int ls, int es
         n *= rad[p];
         fft_pass_any<false>(rad[p], Z, nl, ls, es, n, N, tw);
         __syncthreads();
+    }
+}
+
+// ---- compile-time plans: the same greedy radix order as the host's factor_radices (8, 4, 2, 3), with
+// every size a constant so that the index arithmetic of the passes folds to shifts and multiplies
+constexpr int pick_radix(int n) { return n % 8 == 0 ? 8 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : 3)); }
+
+template <int N, int n>
+__device__ __forceinline__ void fft_lines_fwd_t(double2 *Z, int nl, int ls, int es, const double2 *tw) {
+    if constexpr (n > 1) {
+        constexpr int R = pick_radix(n);
+        fft_pass<R, true>(Z, nl, ls, es, n, N, tw);
+        __syncthreads();
+        fft_lines_fwd_t<N, n / R>(Z, nl, ls, es, tw);
+    }
+}
+template <int N, int n>
+__device__ __forceinline__ void fft_lines_inv_t(double2 *Z, int nl, int ls, int es, const double2 *tw) {
+    if constexpr (n > 1) {
+        constexpr int R = pick_radix(n);
+        fft_lines_inv_t<N, n / R>(Z, nl, ls, es, tw);
+        fft_pass<R, false>(Z, nl, ls, es, n, N, tw);
+        __syncthreads();
+    }
+}
+// NN > 0: compile-time grid size; NN == 0: run-time plan from SpecDev
+template <int NN>
+__device__ __forceinline__ void fft2d_fwd_x(double2 *Z, int N, int LD, int nrad, const int *rad, const double2 *tw) {
+    if constexpr (NN > 0) {
+        fft_lines_fwd_t<NN, NN>(Z, NN, NN + 1, 1, tw);
+        fft_lines_fwd_t<NN, NN>(Z, NN, 1, NN + 1, tw);
+    } else {
+        fft_lines_fwd(Z, N, LD, 1, N, nrad, rad, tw);
+        fft_lines_fwd(Z, N, 1, LD, N, nrad, rad, tw);
+    }
+}
+template <int NN>
+__device__ __forceinline__ void fft2d_inv_x(double2 *Z, int N, int LD, int nrad, const int *rad, const double2 *tw) {
+    if constexpr (NN > 0) {
+        fft_lines_inv_t<NN, NN>(Z, NN, 1, NN + 1, tw);
+        fft_lines_inv_t<NN, NN>(Z, NN, NN + 1, 1, tw);
+    } else {
+        fft_lines_inv(Z, N, 1, LD, N, nrad, rad, tw);
+        fft_lines_inv(Z, N, LD, 1, N, nrad, rad, tw);
     }
 }
 
