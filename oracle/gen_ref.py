@@ -103,21 +103,24 @@ class CNNWeights:
         return cls(cw, cb, g, b, m, v)
 
 
-def cnn_forward(w: CNNWeights, x: np.ndarray, return_layers=False):
+def cnn_forward(w: CNNWeights, x: np.ndarray, return_layers=False, dtype='float32'):
     """AndrewCNN.forward in eval mode (cnn_tools.py:164-176 with div=False,
-    final_activation='None').  x: (B, n_in, N, N) float32 -> (B, n_out, N, N) float32."""
-    t = torch.as_tensor(np.ascontiguousarray(x, dtype='float32'))
+    final_activation='None').  x: (B, n_in, N, N) float32 -> (B, n_out, N, N) float32.
+    dtype='float64' evaluates the same float32 parameters in double precision (the ground truth the
+    rounding error of every float32 / split-f16 evaluation order is measured against)."""
+    td = torch.float64 if dtype == 'float64' else torch.float32
+    T = lambda a: torch.as_tensor(np.asarray(a)).to(td)
+    t = torch.as_tensor(np.ascontiguousarray(x, dtype='float32')).to(td)
     layers = []
     with torch.no_grad():
         for i in range(8):
             k = KERNELS[i]
             p = k // 2
             tp = F.pad(t, (p, p, p, p), mode='circular')
-            t = F.conv2d(tp, torch.as_tensor(w.conv_w[i]), torch.as_tensor(w.conv_b[i]))
+            t = F.conv2d(tp, T(w.conv_w[i]), T(w.conv_b[i]))
             if i < 7:
                 t = F.relu(t)
-                t = F.batch_norm(t, torch.as_tensor(w.bn_m[i]), torch.as_tensor(w.bn_v[i]),
-                                 torch.as_tensor(w.bn_g[i]), torch.as_tensor(w.bn_b[i]),
+                t = F.batch_norm(t, T(w.bn_m[i]), T(w.bn_v[i]), T(w.bn_g[i]), T(w.bn_b[i]),
                                  training=False, eps=BN_EPS)
             if return_layers:
                 layers.append(t.numpy().copy())

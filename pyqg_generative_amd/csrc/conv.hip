@@ -35,12 +35,18 @@ struct ConvArgs {
     const float *bias, *scale, *shift;   // [COUTP]
     int N, R, cout_real;
     size_t npix_total;     // B*N*N (stride of one split-K partial plane)
+    float ascale;          // OUTH: power-of-two pre-scale of the stored 16-bit activations
 };
 
 extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
-template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL, int CSPLIT = 1, bool PARTIAL = false>
+#include "conv_half.hpp"
+
+// OUTH = 0: f32 NHWC output.  OUTH = 1 / 2 (first layer only): the MFMA roles are swapped (lane = pixel)
+// and the epilogue writes the packed f16 / f16 hi-lo activation layout of conv_half.hpp.
+template <int CIN, int COUT, int KS, int CC, int MT, bool PLANAR_IN, bool FINAL, int CSPLIT = 1, bool PARTIAL = false, int OUTH = 0>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+    static_assert(OUTH == 0 || (PLANAR_IN && !FINAL && !PARTIAL), "16-bit output: first layer only");
     constexpr int NTF = (COUT + 31) / 32;        // all output-channel tiles of the layer
     constexpr int NT = NTF / CSPLIT;             // tiles owned by this workgroup (blockIdx.y picks the slice)
     constexpr int COUTP = NTF * 32;
@@ -122,8 +128,10 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = OUTH ? __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                                 (&Bf[nt].x)[e], (&A[mt].x)[e], acc[mt][nt], 0, 0, 0)
+                                           : __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                                 (&A[mt].x)[e], (&Bf[nt].x)[e], acc[mt][nt], 0, 0, 0);
         }
     } else {
         constexpr int G8 = CC / 8;
@@ -224,6 +232,14 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
         const int tile = wave + 4 * mt;
         if (tile >= ntiles) continue;
+        if constexpr (OUTH != 0) {
+            char *pix = reinterpret_cast<char *>(a.out) +
+                        ((size_t)b * N * N + (size_t)y0 * N + tile * 32 + li) * (COUT * 2 * OUTH);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                store_tile_t<OUTH, false>(acc[mt][nt], (nt0 + nt) * 32, h, pix, a.bias, a.scale, a.shift, 1.0f, a.ascale);
+            continue;
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = (nt0 + nt) * 32 + li;
@@ -669,6 +685,8 @@ struct LayerHost {
     LastWeights wv_host;   // last layer, VALU kernel layout (kernel argument)
     float *wl16 = nullptr, *wl8 = nullptr;   // k_conv3 layout [chunk][tap][g8][h][coutp][4], 16- / 8-channel chunks
     float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
+    void *wh[2] = {nullptr, nullptr};        // conv_half.hpp layouts: [0] f16 (NS = 1), [1] f16 hi/lo (NS = 2)
+    float wh_unscale[2] = {1.f, 1.f};        // 2^-s of the power-of-two weight pre-scale
 };
 struct NetHost {
     int n_in, n_out;
@@ -689,6 +707,8 @@ struct qgx_generator {
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
     // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
+    int opt_precision = 0;         // 0 = exact f32 MFMA, 1 = f16 MFMA, 3 = f16x3 split (f32-class accuracy)
+    float opt_ascale = 1.f;        // power-of-two pre-scale of stored 16-bit activations
     int prof_layer = -1;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
     size_t prof_used = 0;
@@ -730,6 +750,38 @@ static int pack_weights(const LayerHost &L, int li, const qgx_cnn_weights *w, bo
     return upf(dst, pw);
 }
 
+// conv_half.hpp weight layout [chunk][tap][j][h][cout][8] f16, pre-scaled by 2^s with max|w| 2^s in [2^13, 2^14)
+static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
+    const int cin = L.cin, cout = L.cout, T = L.ks * L.ks;
+    const int CC = NS == 1 ? 32 : 16, nch = cin / CC;
+    const float *W = w->conv_w[li];
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * T; ++i) mx = fmaxf(mx, fabsf(W[i]));
+    int e = 0;
+    if (mx > 0.f) { (void)frexpf(mx, &e); }             // mx = m 2^e, m in [0.5, 1)
+    int sexp = 14 - e;
+    sexp = sexp < -20 ? -20 : (sexp > 40 ? 40 : sexp);
+    const float sc = ldexpf(1.f, sexp);
+    std::vector<_Float16> pw((size_t)nch * T * 4 * cout * 8, (_Float16)0.f);
+    for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < T; ++t)
+            for (int j = 0; j < 2; ++j)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int co = 0; co < cout; ++co)
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            const int c = NS == 1 ? ch * 32 + j * 16 + hh * 8 + e8 : ch * 16 + hh * 8 + e8;
+                            const float x = W[((size_t)co * cin + c) * T + t] * sc;
+                            const _Float16 xh = (_Float16)x;
+                            const _Float16 v = (NS == 1 || j == 0) ? xh : (_Float16)(x - (float)xh);
+                            pw[(((((size_t)ch * T + t) * 2 + j) * 2 + hh) * cout + co) * 8 + e8] = v;
+                        }
+    void *&dst = L.wh[NS - 1];
+    QGX_HIP(hipMalloc(&dst, pw.size() * sizeof(_Float16)));
+    QGX_HIP(hipMemcpy(dst, pw.data(), pw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    L.wh_unscale[NS - 1] = ldexpf(1.f, -sexp);
+    return QGX_OK;
+}
+
 static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool planar_in) {
     const int cout = L.cout;
     L.coutp = ((cout + 31) / 32) * 32;
@@ -753,6 +805,9 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
                                         w->conv_w[li][((size_t)co * cin + c) * T + t];
                                 }
             if ((rc = upf(cc == 16 ? L.wl16 : L.wl8, pw))) return rc;
+        }
+        if (li < 7) {
+            if ((rc = pack_half(L, li, w, 1)) || (rc = pack_half(L, li, w, 2))) return rc;
         }
     }
     if (li == 7) {      // [tap][c][2] for the VALU last-layer kernel
@@ -800,7 +855,7 @@ static int prof_begin(qgx_generator *g, int layer, hipStream_t st, hipEvent_t &s
     return QGX_OK;
 }
 
-template <int CIN, int COUT, int KS, int CC, bool PLANAR_IN, bool FINAL, int CSPLIT = 1>
+template <int CIN, int COUT, int KS, int CC, bool PLANAR_IN, bool FINAL, int CSPLIT = 1, int OUTH = 0>
 static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                        int N, int cout_real, hipStream_t st) {
     hipEvent_t prof_stop;
@@ -808,19 +863,19 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
     const int R = choose_rows(N);
     QGX_REQUIRE(R > 0 && N % R == 0, "generator: unsupported grid size N=%d", N);
     const int ntiles = R * N / 32;
-    ConvArgs a;
+    ConvArgs a = {};
     a.in = in; a.out = out; a.w = (!PLANAR_IN && CC == 32) ? L.w32 : L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
-    a.N = N; a.R = R; a.cout_real = cout_real; a.npix_total = (size_t)B * N * N;
+    a.N = N; a.R = R; a.cout_real = cout_real; a.npix_total = (size_t)B * N * N; a.ascale = g->opt_ascale;
     constexpr int STRIDE = PLANAR_IN ? CIN : CC + 4;
     const size_t lds = (size_t)(R + KS - 1) * N * STRIDE * sizeof(float);
     QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
     dim3 grid(B * (N / R), CSPLIT), block(256);
     if (ntiles <= 8) {
-        auto kern = k_conv<CIN, COUT, KS, CC, 2, PLANAR_IN, FINAL, CSPLIT>;
+        auto kern = k_conv<CIN, COUT, KS, CC, 2, PLANAR_IN, FINAL, CSPLIT, false, OUTH>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     } else {
-        auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL, CSPLIT>;
+        auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL, CSPLIT, false, OUTH>;
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     }
@@ -861,7 +916,7 @@ static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, co
         QGX_HIP(hipMalloc((void **)&g->part, npix * COUT * nsplit * sizeof(float)));
         g->part_elems = npix * COUT * nsplit;
     }
-    ConvArgs a;
+    ConvArgs a = {};
     a.in = in; a.out = nsplit > 1 ? g->part : out; a.w = L.w32; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = COUT; a.npix_total = npix;
     const size_t lds = (size_t)(R + KS - 1) * N * (CC + 4) * sizeof(float);
@@ -903,7 +958,7 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
     const int ppt = (((PF4 + NSL - 1) / NSL) + NW * 64 - 1) / (NW * 64);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
-    ConvArgs a;
+    ConvArgs a = {};
     a.in = in; a.out = out; a.w = CC == 16 ? L.wl16 : L.wl8; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = COUT;
     const int total_tiles = B * (N / R);
@@ -964,7 +1019,7 @@ static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *i
     QGX_REQUIRE(R > 0 && N % R == 0, "generator: unsupported grid size N=%d", N);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, 7, st, prof_stop); if (prc) return prc; }
-    ConvArgs a;
+    ConvArgs a = {};
     a.in = in; a.out = out; a.w = nullptr; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = n_out;
     const size_t lds = (size_t)(R + 2) * N * 36 * sizeof(float);
@@ -975,6 +1030,77 @@ static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *i
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
+}
+
+// ---- 16-bit matrix-core path (conv_half.hpp) ------------------------------------------------------
+// rows per 8-wave workgroup: 16 or 24 M-tiles of 32 pixels
+static int rows_half(int N) {
+    int R = 0;
+    if (N <= 512 && 512 % N == 0) R = 512 / N;
+    else if (N <= 768 && 768 % N == 0) R = 768 / N;
+    if (R == 0 || N % R) return 0;
+    if ((size_t)(R + 4) * N * 80 + 2 * 5 * 4 * 64 * 16 > 160 * 1024 - 256) return 0;
+    return R;
+}
+static bool half_path_ok(int B, int N) {
+    const int R = rows_half(N);
+    return R > 0 && B * (N / R) >= 128;
+}
+
+template <int CIN, int COUT, int KS, int NS, bool OUTF32>
+static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                        hipStream_t st) {
+    constexpr int TPS = KS == 5 ? 5 : 9;
+    const int R = rows_half(N);
+    QGX_REQUIRE(R > 0, "generator: 16-bit path does not support N=%d", N);
+    const int PR = R + KS - 1;
+    const int ntiles = R * N / 32;
+    const int mtv = ntiles / 8;
+    const int ppt = (PR * N * 4 + 511) / 512;
+    const size_t lds = (size_t)PR * N * 80 + (size_t)2 * TPS * 4 * COUT * 16;
+    QGX_REQUIRE(lds <= 160 * 1024 - 256 && (mtv == 2 || mtv == 3) && ntiles % 8 == 0 && ppt <= 10,
+                "generator: 16-bit path tile shape unsupported for N=%d", N);
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    ConvHArgs a;
+    a.in = in; a.out = out; a.w = L.wh[NS - 1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.wh_unscale[NS - 1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.N = N; a.R = R;
+    const int total_tiles = B * (N / R);
+    int grid = 256;
+    if (grid > total_tiles) grid = total_tiles;
+#define QGX_LH(MTV, PPTV)                                                                                     \
+    {                                                                                                         \
+        auto kern = k_convh<CIN, COUT, KS, NS, MTV, TPS, PPTV, OUTF32>;                                       \
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);                             \
+    }
+    if (mtv == 2) { if (ppt <= 6) QGX_LH(2, 6) else QGX_LH(2, 10) }
+    else { if (ppt <= 6) QGX_LH(3, 6) else QGX_LH(3, 10) }
+#undef QGX_LH
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
+}
+
+static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *in, float *out, int B, int N,
+                            int n_out, hipStream_t st);
+
+template <int NS>
+static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x, float *y, int B, int N,
+                            hipStream_t st) {
+    int rc;
+    float *A = g->actA, *Bb = g->actB;
+    if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false, 2, NS>(g, 0, net.L[0], x, A, B, N, 128, st);
+    else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], x, A, B, N, 128, st);
+    if (rc) return rc;
+    if ((rc = launch_convh<128, 64, 5, NS, false>(g, 1, net.L[1], A, Bb, B, N, st))) return rc;
+    if ((rc = launch_convh<64, 32, 3, NS, false>(g, 2, net.L[2], Bb, A, B, N, st))) return rc;
+    if ((rc = launch_convh<32, 32, 3, NS, false>(g, 3, net.L[3], A, Bb, B, N, st))) return rc;
+    if ((rc = launch_convh<32, 32, 3, NS, false>(g, 4, net.L[4], Bb, A, B, N, st))) return rc;
+    if ((rc = launch_convh<32, 32, 3, NS, false>(g, 5, net.L[5], A, Bb, B, N, st))) return rc;
+    if ((rc = launch_convh<32, 32, 3, NS, true>(g, 6, net.L[6], Bb, A, B, N, st))) return rc;
+    return launch_conv_last(g, net.L[7], A, y, B, N, net.n_out, st);
 }
 
 static int reserve(qgx_generator *g, int B, int N) {
@@ -996,6 +1122,8 @@ static int reserve(qgx_generator *g, int B, int N) {
 static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, float *y, int B, int N,
                        hipStream_t st) {
     int rc;
+    if (g->opt_precision && half_path_ok(B, N))
+        return g->opt_precision == 1 ? cnn_forward_half<1>(g, net, x, y, B, N, st) : cnn_forward_half<2>(g, net, x, y, B, N, st);
     float *A = g->actA, *Bb = g->actB;
     if (net.n_in == 4) rc = g->opt_first_split == 2 ? launch_conv<4, 128, 5, 4, true, false, 2>(g, 0, net.L[0], x, A, B, N, 128, st)
                        : g->opt_first_split == 4 ? launch_conv<4, 128, 5, 4, true, false, 4>(g, 0, net.L[0], x, A, B, N, 128, st)
@@ -1096,6 +1224,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             LayerHost &L = g->nets[n].L[li];
             float *ptrs[] = {L.w, L.w32, L.wl16, L.wl8, L.bias, L.scale, L.shift};
             for (float *p : ptrs) if (p) (void)hipFree(p);
+            for (void *p : L.wh) if (p) (void)hipFree(p);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
     for (float *p : bufs) if (p) (void)hipFree(p);
@@ -1145,6 +1274,8 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "last_valu")) g->opt_last_valu = value ? 1 : 0;
     else if (!strcmp(name, "small")) g->opt_small = value ? 1 : 0;
     else if (!strcmp(name, "v3")) g->opt_v3 = value;   // -1 auto, 0 off, 1 = slice per tap row, 2 = per chunk
+    else if (!strcmp(name, "precision")) { QGX_REQUIRE(value == 0 || value == 1 || value == 3, "precision must be 0 (f32), 1 (f16) or 3 (f16x3)"); g->opt_precision = value; }
+    else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= 0 && value <= 12, "ascale_log2 must be in 0..12"); g->opt_ascale = ldexpf(1.f, value); }
     else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;

@@ -1,0 +1,91 @@
+"""GPU: the generator's 16-bit matrix-core paths against the float32 path and a float64 ground truth.
+
+The CNN's parameters and inputs are float32; `oracle.gen_ref.cnn_forward(dtype='float64')` evaluates
+them in double precision, so |result - truth| is the rounding error of an evaluation order.
+  * precision 0: exact f32 MFMA (v_mfma_f32_32x32x2_f32)
+  * precision 3: f16 hi/lo split, three f16 MFMAs per product, f32 accumulate — must stay in the
+    float32 error class: it has to pass the SAME 2e-5 golden-vector tolerance as precision 0 and
+    its error against the float64 truth may not exceed 4x that of the reference's own float32
+    evaluation (torch CPU) on the same input
+  * precision 1: plain f16 operands (TF32-class, 2^-11 operand rounding): 1e-2 of the field maximum
+"""
+import os
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from conftest import golden, GOLDEN
+from oracle import gen_ref
+
+
+def _gpu_generator(kind):
+    import pyqg_generative_amd as qa
+    from pyqg_generative_amd import weights
+    nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind)
+    return qa.Generator(kind, nets, xs, ys)
+
+
+def _oracle_nets(kind):
+    d = golden(f'weights_{kind}.npz')
+    nets = [gen_ref.CNNWeights.from_npz_dict(d, 'net0_')]
+    if kind == 'gz':
+        nets.append(gen_ref.CNNWeights.from_npz_dict(d, 'net1_'))
+    return nets
+
+
+def _maxrel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+@pytest.mark.parametrize('kind,N,B', [('gan', 64, 32), ('vae', 96, 24), ('gz', 48, 48), ('gan', 32, 32), ('gan', 128, 16)])
+def test_split_f16_is_float32_class(kind, N, B):
+    gen = _gpu_generator(kind)
+    nets = _oracle_nets(kind)
+    rs = np.random.RandomState(N + B)
+    n_in = nets[0].n_in
+    x = rs.randn(B, n_in, N, N).astype('float32')
+    x[:, :2] *= 1.5                                   # q / x_std is O(1) with a heavier tail than z
+    xd = torch.as_tensor(x, device='cuda')
+    for inet, w in enumerate(nets):
+        truth = gen_ref.cnn_forward(w, x[:4], dtype='float64')
+        ref32 = gen_ref.cnn_forward(w, x[:4])
+        err_ref = _maxrel(ref32, truth)
+        errs = {}
+        for prec in (0, 3, 1):
+            gen.set_option('precision', prec)
+            y = gen.cnn_forward(xd, inet).cpu().numpy()
+            errs[prec] = _maxrel(y[:4], truth)
+        gen.set_option('precision', 0)
+        print(f'\n{kind} net{inet} N={N}: max err / max|y| vs float64 truth: torch-f32 {err_ref:.2e}, '
+              f'f32 MFMA {errs[0]:.2e}, f16x3 {errs[3]:.2e}, f16 {errs[1]:.2e}')
+        assert errs[0] < 2e-5
+        assert errs[3] < 2e-5
+        assert errs[3] < 4 * max(err_ref, errs[0]) + 1e-7
+        assert errs[1] < 1e-2
+
+
+@pytest.mark.parametrize('kind', ['gan', 'vae', 'gz'])
+def test_split_f16_golden_vectors(kind):
+    """the reference's own outputs (Parameterization.__call__, tests/golden/generator.npz) at the
+    float32 tolerance, with the ensemble padded by random members so that the 16-bit path engages"""
+    d = golden('generator.npz')
+    gen = _gpu_generator(kind)
+    gen.set_option('precision', 3)
+    for N in (48, 64, 96):
+        q = d[f'{kind}_{N}_q'].astype('float64')
+        z = d[f'{kind}_{N}_z']
+        S_ref = d[f'{kind}_{N}_S']
+        B = 40
+        rs = np.random.RandomState(N)
+        qb = np.concatenate([q[None], rs.randn(B - 1, 2, N, N) * np.abs(q).max() / 3], 0)
+        if kind == 'gz':
+            zb = np.concatenate([z.reshape(1, 2, N, N), rs.randn(B - 1, 2, N, N)], 0).astype('float64')
+        else:
+            zb = np.concatenate([z.reshape(1, 2, N, N), rs.randn(B - 1, 2, N, N)], 0).astype('float32')
+        S = gen.forward(torch.as_tensor(qb, device='cuda'), torch.as_tensor(zb, device='cuda'), demean=True)
+        S = S.cpu().numpy()[0]
+        err = (np.abs(S - S_ref) / np.abs(S_ref).max(axis=(1, 2), keepdims=True)).max()
+        print(f'\n{kind} N={N}: f16x3 vs golden {err:.2e}')
+        assert err < 2e-5
