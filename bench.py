@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 
 MAC_PER_PIXEL = [12800, 204800, 18432, 9216, 9216, 9216, 9216, 576]   # SURVEY §8(d), GAN/VAE nets
 F32_MFMA_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md
+F16_MFMA_PEAK_TFLOPS = 2500.0                                          # dense f16/bf16, same guide
+PRECISIONS = {'f32': 0, 'f16x3': 3, 'f16': 1}
 
 
 def eddy_like_q(member_ids, N):
@@ -104,6 +106,10 @@ def main():
     ap.add_argument('--members', type=int, default=128, help='ensemble members PER GPU')
     ap.add_argument('--nx', type=int, default=64)
     ap.add_argument('--kind', default='gan', choices=['gan', 'vae', 'gz'])
+    ap.add_argument('--precision', default='f16x3', choices=list(PRECISIONS),
+                    help='generator conv arithmetic: f16x3 = hi/lo split f16 MFMA, f32-class accuracy (default); '
+                         'f32 = exact f32 MFMA; f16 = plain f16 operands (TF32-class)')
+    ap.add_argument('--no-f32-aux', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-b1', action='store_true')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -132,6 +138,7 @@ def main():
     N, B, K, W = args.nx, args.members, args.steps, args.warmup
     dt = 14400. if N <= 64 else (7200. if N <= 128 else 3600.)      # tools/parameters.py:12-31
     gen, wsrc = load_generator(args.kind, local_rank)
+    gen.set_option('precision', PRECISIONS[args.precision])
     eng = qa.EnsembleEngine(nx=N, n_members=B, device=local_rank, dt=dt)
     ids = np.arange(rank * B, (rank + 1) * B)
     eng.set_q(eddy_like_q(ids, N))
@@ -179,25 +186,59 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
+        # peak for ALGORITHMIC flops: f16x3 executes three f16 MFMAs per algorithmic multiply-add
+        mfma_per_mac = {'f32': 1, 'f16x3': 3, 'f16': 1}[args.precision]
+        peak = F32_MFMA_PEAK_TFLOPS if args.precision == 'f32' else F16_MFMA_PEAK_TFLOPS / mfma_per_mac
+        dtype = {'f32': 'f64 spectral core + f32 generator (exact-f32 MFMA)',
+                 'f16x3': 'f64 spectral core + f32-class generator: f16 hi/lo split operands, 3 f16 MFMAs per '
+                          'product, f32 accumulate (error vs a float64 ground truth <= the exact-f32 path, '
+                          'tests/test_gpu_precision.py)',
+                 'f16': 'f64 spectral core + f16-operand generator (f32 accumulate, TF32-class)'}[args.precision]
+        kname = 'k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh<128,64,5x5>'
         out = {
             'metric': 'ensemble-timesteps/sec, 64^2 2-layer eddy + GAN param',
             'value': value, 'unit': 'ensemble-timesteps/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64 spectral core + f32 generator (exact-f32 MFMA)',
+            'vs_baseline': None, 'dtype': dtype,
             'data': f'synthetic band-limited PV fields (seeded per member); generator weights: {wsrc}',
             'config': {'workload': f'eddy {N}x{N} 2-layer + {args.kind.upper()} parameterization, '
                                    f'{B} members per GPU (BASELINE configs[2] shard: 1024 members / 8 GPUs), '
                                    f"sampling='constant' nsteps=1, dt={dt:.0f}s",
                        'members_per_gpu': B, 'total_members': total_members, 'nx': N,
+                       'generator_precision': args.precision,
                        'parallelism': f'ensemble-sharded x{world}, no data-path collective'},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_conv<128,64,5x5> (generator layer 2)',
-                         'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'kernel': f'{kname} (generator layer 2)',
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic if args.precision == 'f32' else None,
                          'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_s * 1e3,
                          'launches_timed': l2_n,
+                         'executed_mfma_tflops': achieved * mfma_per_mac,
+                         'peak_note': ('157.3 TFLOP/s dense f32 MFMA' if args.precision == 'f32' else
+                                       f'2500 TFLOP/s dense f16 MFMA / {mfma_per_mac} MFMAs per algorithmic MAC; a bare '
+                                       'MFMA loop with this operand traffic sustains 1456 TFLOP/s on random data '
+                                       '(clock held at 1.66 GHz under load, bench_tools/mfma_peak_f16.hip)'),
                          'whole_step_generator_tflops': gen_flop_per_member_step * value / world / 1e12},
             'healthy': healthy,
         }
+
+    # the same workload on the exact-f32 matrix cores (auxiliary: round-to-round continuity)
+    if world == 1 and args.precision != 'f32' and not args.no_f32_aux:
+        gen.set_option('precision', 0)
+        eng.step(W, **step_kw)
+        torch.cuda.synchronize()
+        gen.profile(1)
+        t0 = time.perf_counter()
+        eng.step(K, **step_kw)
+        torch.cuda.synchronize()
+        el32 = time.perf_counter() - t0
+        ms32, n32 = gen.profile_read()
+        gen.profile(-1)
+        gen.set_option('precision', PRECISIONS[args.precision])
+        a32 = 2.0 * MAC_PER_PIXEL[1] * N * N * B / ((ms32 / max(n32, 1)) * 1e-3) / 1e12
+        out['exact_f32'] = {'value': B * K / el32, 'unit': 'ensemble-timesteps/sec', 'ms_per_step': 1e3 * el32 / K,
+                            'roofline': {'bound': 'mfma', 'kernel': 'k_conv<128,64,5x5> (generator layer 2)',
+                                         'achieved': a32, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                         'frac': a32 / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic}}
 
     # configs[1]: the single-member, launch-latency-bound case (auxiliary number)
     if world == 1 and not args.no_b1:

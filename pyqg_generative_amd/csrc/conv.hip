@@ -707,7 +707,8 @@ struct qgx_generator {
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
     // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
-    int opt_precision = 0;         // 0 = exact f32 MFMA, 1 = f16 MFMA, 3 = f16x3 split (f32-class accuracy)
+    int opt_precision = 3;         // 0 = exact f32 MFMA, 1 = f16 MFMA, 3 = f16x3 split (f32-class accuracy; default
+                                   // wherever the ensemble fills the 8-wave tiles, see half_path_ok)
     float opt_ascale = 1.f;        // power-of-two pre-scale of stored 16-bit activations
     int prof_layer = -1;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
