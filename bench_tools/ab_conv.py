@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import pyqg_generative_amd as qa
 from pyqg_generative_amd import weights
 
-OPTS = {'chunk': 32, 'last_valu': 1, 'first_split': 2, 'v3': -1, 'precision': 0, 'ascale_log2': 0}      # option -> default
+OPTS = {'chunk': 32, 'last_valu': 1, 'first_split': 2, 'v3': -1, 'precision': 0, 'ascale_log2': 0, 'first_h': 1, 'half_nw': 8, 'member_chunk': 0, 'res': 1, 'h2': 2}      # option -> default
 MAC = [12800, 204800, 18432, 9216, 9216, 9216, 9216, 576]
 
 
@@ -57,6 +57,22 @@ def main():
                 ms, n = gen.profile_read()
                 res[(vi, l)].append(ms / max(n, 1))
     gen.profile(-1)
+    # whole forward, interleaved
+    tot = {vi: [] for vi in range(len(variants))}
+    for r in range(args.rounds):
+        for vi in np.random.permutation(len(variants)):
+            v = variants[vi]
+            for k in OPTS:
+                gen.set_option(k, v.get(k, OPTS[k]))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                gen.cnn_forward(x)
+            e1.record()
+            torch.cuda.synchronize()
+            tot[vi].append(e0.elapsed_time(e1) / 5 * 1e3)
+    for vi, v in enumerate(variants):
+        print(f'  whole forward {str(v):55s} {np.median(tot[vi]):9.1f} us')
     print(f'B={B} N={N}; times in us (median / min over {args.rounds} rounds); TF = algorithmic TFLOP/s at the median')
     for l in layers:
         flop = 2.0 * MAC[l] * N * N * B

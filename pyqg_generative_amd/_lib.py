@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libqgx.so')
+LIB_PATH = os.environ.get('QGX_LIB') or os.path.join(_HERE, 'libqgx.so')   # QGX_LIB: developer builds only
 
 
 class QgxError(RuntimeError):

@@ -687,6 +687,8 @@ struct LayerHost {
     float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
     void *wh[2] = {nullptr, nullptr};        // conv_half.hpp layouts: [0] f16 (NS = 1), [1] f16 hi/lo (NS = 2)
     float wh_unscale[2] = {1.f, 1.f};        // 2^-s of the power-of-two weight pre-scale
+    void *whf = nullptr;                     // first layer, f16x3: [step][part][h][128][8] f16
+    float whf_unscale = 1.f;
 };
 struct NetHost {
     int n_in, n_out;
@@ -707,6 +709,13 @@ struct qgx_generator {
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
     // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
+    unsigned long long *stamps = nullptr;   // diagnostic builds only
+    int stamp_layer = -1;
+    int opt_h2 = 2;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
+    int opt_res = 1;               // f16x3 3x3 layers: resident-weight kernel where its tile fits in LDS
+    int opt_member_chunk = 0;      // 16-bit path: members per sub-batch (0 = whole ensemble)
+    int opt_half_nw = 8;           // 16-bit hidden layers: 4 waves x 2 workgroups per CU, or 8 x 1
+    int opt_first_h = 1;           // f16x3 path: first layer on the 16-bit cores too (0: exact-f32 MFMA first layer)
     int opt_precision = 3;         // 0 = exact f32 MFMA, 1 = f16 MFMA, 3 = f16x3 split (f32-class accuracy; default
                                    // wherever the ensemble fills the 8-wave tiles, see half_path_ok)
     float opt_ascale = 1.f;        // power-of-two pre-scale of stored 16-bit activations
@@ -783,12 +792,44 @@ static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
     return QGX_OK;
 }
 
+// first layer, f16x3 (k_convh_first): [step][part][h][cout][8], element j of lane half h in step s is
+// (tap, channel) = (TPS s + TPF h + j / n_in, j % n_in); tap slots >= 25 hold zeros
+static int pack_half_first(LayerHost &L, const qgx_cnn_weights *w) {
+    const int nin = L.cin, cout = L.cout, T = 25;
+    const int TPF = 8 / nin, TPS = 2 * TPF, nstep = (T + TPS - 1) / TPS;
+    const float *W = w->conv_w[0];
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)cout * nin * T; ++i) mx = fmaxf(mx, fabsf(W[i]));
+    int e = 0;
+    if (mx > 0.f) (void)frexpf(mx, &e);
+    int sexp = 14 - e;
+    sexp = sexp < -20 ? -20 : (sexp > 40 ? 40 : sexp);
+    const float sc = ldexpf(1.f, sexp);
+    std::vector<_Float16> pw((size_t)nstep * 4 * cout * 8, (_Float16)0.f);
+    for (int s = 0; s < nstep; ++s)
+        for (int part = 0; part < 2; ++part)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int co = 0; co < cout; ++co)
+                    for (int j = 0; j < 8; ++j) {
+                        const int tap = TPS * s + TPF * hh + j / nin, c = j % nin;
+                        if (tap >= T) continue;
+                        const float x = W[((size_t)co * nin + c) * T + tap] * sc;
+                        const _Float16 xh = (_Float16)x;
+                        pw[((((size_t)s * 2 + part) * 2 + hh) * cout + co) * 8 + j] = part == 0 ? xh : (_Float16)(x - (float)xh);
+                    }
+    QGX_HIP(hipMalloc(&L.whf, pw.size() * sizeof(_Float16)));
+    QGX_HIP(hipMemcpy(L.whf, pw.data(), pw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    L.whf_unscale = ldexpf(1.f, -sexp);
+    return QGX_OK;
+}
+
 static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool planar_in) {
     const int cout = L.cout;
     L.coutp = ((cout + 31) / 32) * 32;
     int rc;
     if (planar_in) {
         if ((rc = pack_weights(L, li, w, true, L.cin, L.w))) return rc;
+        if ((rc = pack_half_first(L, w))) return rc;
     } else {
         if ((rc = pack_weights(L, li, w, false, 16, L.w))) return rc;
         if ((rc = pack_weights(L, li, w, false, 32, L.w32))) return rc;
@@ -1043,41 +1084,53 @@ static int rows_half(int N) {
     if ((size_t)(R + 4) * N * 80 + 2 * 5 * 4 * 64 * 16 > 160 * 1024 - 256) return 0;
     return R;
 }
-static bool half_path_ok(int B, int N) {
-    const int R = rows_half(N);
-    return R > 0 && B * (N / R) >= 128;
+static bool half_path_ok(const qgx_generator *g, int B, int N) {
+    const int R = g->opt_half_nw == 4 ? choose_rows(N) : rows_half(N);
+    if (R <= 0 || N % R || N > 128 || choose_rows(N) <= 0) return false;
+    return B * (N / R) >= (g->opt_half_nw == 4 ? 256 : 128);
 }
 
 template <int CIN, int COUT, int KS, int NS, bool OUTF32>
 static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
                         hipStream_t st) {
     constexpr int TPS = KS == 5 ? 5 : 9;
-    const int R = rows_half(N);
-    QGX_REQUIRE(R > 0, "generator: 16-bit path does not support N=%d", N);
+    // two shapes: 4 waves x 2 workgroups per CU (swizzled 64-byte patch pixels; the two workgroups run out
+    // of phase, so one's staging overlaps the other's MFMAs) or 8 waves x 1 workgroup (double-height tiles)
+    const bool four = g->opt_half_nw == 4;
+    const int R = four ? choose_rows(N) : rows_half(N);
+    QGX_REQUIRE(R > 0 && N % R == 0, "generator: 16-bit path does not support N=%d", N);
+    const int nw = four ? 4 : 8;
     const int PR = R + KS - 1;
     const int ntiles = R * N / 32;
-    const int mtv = ntiles / 8;
-    const int ppt = (PR * N * 4 + 511) / 512;
-    const size_t lds = (size_t)PR * N * 80 + (size_t)2 * TPS * 4 * COUT * 16;
-    QGX_REQUIRE(lds <= 160 * 1024 - 256 && (mtv == 2 || mtv == 3) && ntiles % 8 == 0 && ppt <= 10,
+    const int mtv = ntiles / nw;
+    const int ppt = (PR * N * 4 + nw * 64 - 1) / (nw * 64);
+    const size_t lds = (size_t)PR * N * (four ? 64 : 80) + (size_t)2 * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
+    QGX_REQUIRE(lds <= 160 * 1024 - 256 && (mtv == 2 || mtv == 3) && ntiles % nw == 0 && ppt <= 12,
                 "generator: 16-bit path tile shape unsupported for N=%d", N);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
-    ConvHArgs a;
+    ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[NS - 1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[NS - 1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
     a.N = N; a.R = R;
+    a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (N / R);
-    int grid = 256;
+    int grid = 256 * (lds * 2 <= 160 * 1024 ? 2 : 1);
     if (grid > total_tiles) grid = total_tiles;
-#define QGX_LH(MTV, PPTV)                                                                                     \
+#define QGX_LH(MTV, PPTV, NWV, SWZV)                                                                          \
     {                                                                                                         \
-        auto kern = k_convh<CIN, COUT, KS, NS, MTV, TPS, PPTV, OUTF32>;                                       \
+        auto kern = k_convh<CIN, COUT, KS, NS, MTV, TPS, PPTV, OUTF32, NWV, SWZV>;                            \
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);                             \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, a, total_tiles);                        \
     }
-    if (mtv == 2) { if (ppt <= 6) QGX_LH(2, 6) else QGX_LH(2, 10) }
-    else { if (ppt <= 6) QGX_LH(3, 6) else QGX_LH(3, 10) }
+    if (four) {
+        if (mtv == 2) { if (ppt <= 6) QGX_LH(2, 6, 4, true) else if (ppt <= 8) QGX_LH(2, 8, 4, true) else QGX_LH(2, 12, 4, true) }
+        else QGX_LH(3, 12, 4, true)
+    } else {
+        QGX_REQUIRE(ppt <= 10, "generator: 16-bit path tile shape unsupported for N=%d", N);
+        if (mtv == 2) { if (ppt <= 6) QGX_LH(2, 6, 8, false) else QGX_LH(2, 10, 8, false) }
+        else { if (ppt <= 6) QGX_LH(3, 6, 8, false) else QGX_LH(3, 10, 8, false) }
+    }
 #undef QGX_LH
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
@@ -1087,21 +1140,149 @@ static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const v
 static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *in, float *out, int B, int N,
                             int n_out, hipStream_t st);
 
+// f16x3 hidden layers at the grid sizes with a compile-time specialisation (k_convh2, 2 workgroups per CU)
+template <int CIN, int COUT, int KS, bool OUTF32>
+static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                         hipStream_t st, bool &done) {
+    done = false;
+    if (N != 64) return QGX_OK;
+    constexpr int NN = 64, MT = 2, TPS = KS == 5 ? 5 : 9;
+    constexpr bool WDB = KS == 3;
+    constexpr int R = 4 * MT * 32 / NN, PR = R + KS - 1, PW = NN + 2 * (KS / 2);
+    constexpr size_t lds = (size_t)PR * PW * 80 + (size_t)(WDB ? 2 : 1) * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
+    static_assert(lds * 2 <= 160 * 1024, "two workgroups per CU");
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    ConvHArgs a = {};
+    a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.N = N; a.R = R;
+    const int total_tiles = B * (N / R);
+    int grid = 512;
+    if (grid > total_tiles) grid = total_tiles;
+    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB>;
+    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    done = true;
+    return QGX_OK;
+}
+
+// 3x3 layers, f16x3, resident weights (k_convh_res); done = false when the tile does not fit in LDS
+template <int CIN, int COUT, bool OUTF32>
+static int launch_convh_res(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                            hipStream_t st, bool &done) {
+    done = false;
+    const int R = rows_half(N);
+    if (R <= 0 || N % R) return QGX_OK;
+    const int PR = R + 2, ntiles = R * N / 32, mtv = ntiles / 8;
+    const size_t lds = (size_t)(CIN / 16) * 9 * 4 * COUT * 16 + (size_t)PR * N * 128 + 3 * COUT * sizeof(float);
+    const int ppt = (PR * N * 8 + 511) / 512;
+    if (lds > 160 * 1024 || ntiles % 8 || (mtv != 2 && mtv != 3) || ppt > 14) return QGX_OK;
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    ConvHArgs a = {};
+    a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.N = N; a.R = R;
+    a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
+    const int total_tiles = B * (N / R);
+    int grid = 256;
+    if (grid > total_tiles) grid = total_tiles;
+#define QGX_LR(MTV, PPTV)                                                                                     \
+    {                                                                                                         \
+        auto kern = k_convh_res<CIN, COUT, MTV, PPTV, OUTF32>;                                                \
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);                             \
+    }
+    if (mtv == 2) { if (ppt <= 10) QGX_LR(2, 10) else QGX_LR(2, 14) }
+    else { if (ppt <= 10) QGX_LR(3, 10) else QGX_LR(3, 14) }
+#undef QGX_LR
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    done = true;
+    return QGX_OK;
+}
+
+template <int CIN, int COUT, int NS, bool OUTF32>
+static int conv3x3_half(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                        hipStream_t st) {
+    if (NS == 2 && g->opt_h2) {
+        bool done = false;
+        int rc = launch_convh2<CIN, COUT, 3, OUTF32>(g, layer, L, in, out, B, N, st, done);
+        if (rc || done) return rc;
+    }
+    if (NS == 2 && g->opt_res) {
+        bool done = false;
+        int rc = launch_convh_res<CIN, COUT, OUTF32>(g, layer, L, in, out, B, N, st, done);
+        if (rc || done) return rc;
+    }
+    return launch_convh<CIN, COUT, 3, NS, OUTF32>(g, layer, L, in, out, B, N, st);
+}
+
+template <int NIN>
+static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float *in, void *out, int B, int N,
+                              hipStream_t st) {
+    const int R = choose_rows(N);
+    QGX_REQUIRE(R > 0 && N % R == 0 && N % 4 == 0, "generator: unsupported grid size N=%d", N);
+    const int PR = R + 4, ntiles = R * N / 32;
+    constexpr int nstep = NIN == 4 ? 7 : 4;
+    const size_t lds = (size_t)nstep * 4 * 128 * 16 + (size_t)2 * PR * N * NIN * 4 + 3 * 128 * sizeof(float);
+    const int ppt = (PR * NIN * (N / 4) + 255) / 256;
+    QGX_REQUIRE(lds <= 160 * 1024 - 256 && ppt <= 3 && (ntiles == 8 || ntiles == 12),
+                "generator: 16-bit first layer unsupported for N=%d", N);
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, 0, st, prof_stop); if (prc) return prc; }
+    ConvHFirstArgs a;
+    a.in = in; a.out = out; a.w = L.whf; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.whf_unscale; a.ascale = g->opt_ascale; a.N = N; a.R = R;
+    const int total_tiles = B * (N / R);
+    const int wgs = lds * 2 <= 160 * 1024 ? 2 : 1;
+    int grid = 256 * wgs;
+    if (grid > total_tiles) grid = total_tiles;
+#define QGX_LF(MTV, PPTV)                                                                                     \
+    {                                                                                                         \
+        auto kern = k_convh_first<NIN, MTV, PPTV>;                                                            \
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);                             \
+    }
+    if (ntiles == 8) { if (ppt <= 2) QGX_LF(2, 2) else QGX_LF(2, 3) }
+    else { if (ppt <= 2) QGX_LF(3, 2) else QGX_LF(3, 3) }
+#undef QGX_LF
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
+}
+
 template <int NS>
 static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x, float *y, int B, int N,
                             hipStream_t st) {
     int rc;
     float *A = g->actA, *Bb = g->actB;
-    if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false, 2, NS>(g, 0, net.L[0], x, A, B, N, 128, st);
-    else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], x, A, B, N, 128, st);
-    if (rc) return rc;
-    if ((rc = launch_convh<128, 64, 5, NS, false>(g, 1, net.L[1], A, Bb, B, N, st))) return rc;
-    if ((rc = launch_convh<64, 32, 3, NS, false>(g, 2, net.L[2], Bb, A, B, N, st))) return rc;
-    if ((rc = launch_convh<32, 32, 3, NS, false>(g, 3, net.L[3], A, Bb, B, N, st))) return rc;
-    if ((rc = launch_convh<32, 32, 3, NS, false>(g, 4, net.L[4], Bb, A, B, N, st))) return rc;
-    if ((rc = launch_convh<32, 32, 3, NS, false>(g, 5, net.L[5], A, Bb, B, N, st))) return rc;
-    if ((rc = launch_convh<32, 32, 3, NS, true>(g, 6, net.L[6], Bb, A, B, N, st))) return rc;
-    return launch_conv_last(g, net.L[7], A, y, B, N, net.n_out, st);
+    // optional member sub-batches ("member_chunk"): all layers of one sub-batch before the next, so that the
+    // inter-layer activations of a sub-batch can stay in the 256 MB Infinity Cache
+    const int mc = g->opt_member_chunk > 0 && g->opt_member_chunk < B ? g->opt_member_chunk : B;
+    for (int b0 = 0; b0 < B; b0 += mc) {
+        const int Bc = B - b0 < mc ? B - b0 : mc;
+        const float *xc = x + (size_t)b0 * net.n_in * N * N;
+        float *yc = y + (size_t)b0 * net.n_out * N * N;
+        if (NS == 2 && g->opt_first_h) {
+            rc = net.n_in == 4 ? launch_convh_first<4>(g, net.L[0], xc, A, Bc, N, st) : launch_convh_first<2>(g, net.L[0], xc, A, Bc, N, st);
+        } else if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
+        else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
+        if (rc) return rc;
+        bool done1 = false;
+        if (NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, net.L[1], A, Bb, Bc, N, st))) return rc;
+        if ((rc = conv3x3_half<64, 32, NS, false>(g, 2, net.L[2], Bb, A, Bc, N, st))) return rc;
+        if ((rc = conv3x3_half<32, 32, NS, false>(g, 3, net.L[3], A, Bb, Bc, N, st))) return rc;
+        if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], Bb, A, Bc, N, st))) return rc;
+        if ((rc = conv3x3_half<32, 32, NS, false>(g, 5, net.L[5], A, Bb, Bc, N, st))) return rc;
+        if ((rc = conv3x3_half<32, 32, NS, true>(g, 6, net.L[6], Bb, A, Bc, N, st))) return rc;
+        if ((rc = launch_conv_last(g, net.L[7], A, yc, Bc, N, net.n_out, st))) return rc;
+    }
+    return QGX_OK;
 }
 
 static int reserve(qgx_generator *g, int B, int N) {
@@ -1123,7 +1304,7 @@ static int reserve(qgx_generator *g, int B, int N) {
 static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, float *y, int B, int N,
                        hipStream_t st) {
     int rc;
-    if (g->opt_precision && half_path_ok(B, N))
+    if (g->opt_precision && half_path_ok(g, B, N))
         return g->opt_precision == 1 ? cnn_forward_half<1>(g, net, x, y, B, N, st) : cnn_forward_half<2>(g, net, x, y, B, N, st);
     float *A = g->actA, *Bb = g->actB;
     if (net.n_in == 4) rc = g->opt_first_split == 2 ? launch_conv<4, 128, 5, 4, true, false, 2>(g, 0, net.L[0], x, A, B, N, 128, st)
@@ -1226,6 +1407,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             float *ptrs[] = {L.w, L.w32, L.wl16, L.wl8, L.bias, L.scale, L.shift};
             for (float *p : ptrs) if (p) (void)hipFree(p);
             for (void *p : L.wh) if (p) (void)hipFree(p);
+            if (L.whf) (void)hipFree(L.whf);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
     for (float *p : bufs) if (p) (void)hipFree(p);
@@ -1276,11 +1458,25 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "small")) g->opt_small = value ? 1 : 0;
     else if (!strcmp(name, "v3")) g->opt_v3 = value;   // -1 auto, 0 off, 1 = slice per tap row, 2 = per chunk
     else if (!strcmp(name, "precision")) { QGX_REQUIRE(value == 0 || value == 1 || value == 3, "precision must be 0 (f32), 1 (f16) or 3 (f16x3)"); g->opt_precision = value; }
+    else if (!strcmp(name, "member_chunk")) { QGX_REQUIRE(value >= 0, "member_chunk must be >= 0"); g->opt_member_chunk = value; }
+    else if (!strcmp(name, "res")) g->opt_res = value ? 1 : 0;
+    else if (!strcmp(name, "h2")) g->opt_h2 = value & 3;
+    else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
+    else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
     else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= 0 && value <= 12, "ascale_log2 must be in 0..12"); g->opt_ascale = ldexpf(1.f, value); }
     else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;
 }
+
+#ifdef QGX_STAMPS
+// diagnostic builds only (bench_tools/conv_stamps.py): where the s_memtime trace of k_convh_res goes
+extern "C" int qgx_debug_set_stamps(qgx_generator *g, void *buf, int layer) {
+    g->stamps = (unsigned long long *)buf;
+    g->stamp_layer = layer;
+    return QGX_OK;
+}
+#endif
 
 extern "C" int qgx_moments_accumulate(const float *y_dev, double *sum_dev, double *sumsq_dev, size_t n, void *stream) {
     QGX_REQUIRE(y_dev && sum_dev && sumsq_dev && n > 0, "qgx_moments_accumulate: bad argument");

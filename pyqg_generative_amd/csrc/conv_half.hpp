@@ -41,7 +41,15 @@ struct ConvHArgs {
     float unscale;         // 1 / (weight pre-scale * input activation pre-scale), a power of two
     float ascale;          // pre-scale of the stored output activations, a power of two
     int N, R;
+    unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only: s_memtime trace, 64 slots per workgroup
 };
+
+#ifdef QGX_STAMPS
+#define QGX_STAMP()                                                                          \
+    if (a.stamps && threadIdx.x == 0 && stamp_i < 64) a.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memtime();
+#else
+#define QGX_STAMP()
+#endif
 
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
     h2 v = {(_Float16)a, (_Float16)b};
@@ -100,16 +108,18 @@ __device__ __forceinline__ void store_tile_t(const f32x16 &acc, int cb, int h, c
     }
 }
 
-template <int CIN, int COUT, int KS, int NS, int MT, int TPS, int PPT, bool OUTF32>
-__global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
-    constexpr int NW = 8, NTHR = 512;
+template <int CIN, int COUT, int KS, int NS, int MT, int TPS, int PPT, bool OUTF32, int NW = 8, bool SWZ = false>
+__global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles) {
+    constexpr int NTHR = NW * 64;
     constexpr int NT = COUT / 32;
     constexpr int P = KS / 2, T = KS * KS;
     constexpr int CC = NS == 1 ? 32 : 16;
     constexpr int NCH = CIN / CC;
     constexpr int PIXB = CIN * 2 * NS;                  // bytes of one input pixel record
     constexpr int OPIXB = OUTF32 ? COUT * 4 : COUT * 2 * NS;
-    constexpr int PSTR = 80;                            // LDS bytes per patch pixel (64 payload + 16 pad)
+    // LDS bytes per patch pixel: 64 payload + 16 pad, or (SWZ) 64 with the unit index XOR-swizzled by
+    // bits 2..3 of the pixel index — both make every 16-lane ds_read_b128 group conflict-free
+    constexpr int PSTR = SWZ ? 64 : 80;
     constexpr int TAPB = 4 * COUT * 16;                 // weight bytes per tap: [j][h][cout][8 f16]
     constexpr int WSB = TPS * TAPB;
     constexpr int NSL = T / TPS;
@@ -122,6 +132,9 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
     const int PU = PR * N * 4;                          // 16-byte units of the patch payload
     char *const lds0 = conv_smem;
     char *const wlds0 = lds0 + patch_bytes;
+    // epilogue parameters (bias | BN scale | BN shift) live in LDS: a global load in the epilogue would put a
+    // full memory latency, and a wait on the tile's own output stores, on the critical path of every tile
+    float *const ep = reinterpret_cast<float *>(wlds0 + 2 * WSB);
     const char *const inb = reinterpret_cast<const char *>(a.in);
     const char *const wb = reinterpret_cast<const char *>(a.w);
     const int tiles_per_img = N / R;
@@ -150,7 +163,9 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
     {                                                                                                       \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
             const int it_ = u * NTHR + threadIdx.x;                                                          \
-            if (it_ < PU) *reinterpret_cast<f32x4 *>(lds0 + (it_ >> 2) * PSTR + (it_ & 3) * 16) = V[u];     \
+            if (it_ < PU)                                                                                   \
+                *reinterpret_cast<f32x4 *>(lds0 + (it_ >> 2) * PSTR +                                       \
+                                           (SWZ ? ((it_ & 3) ^ ((it_ >> 4) & 3)) : (it_ & 3)) * 16) = V[u];  \
         }                                                                                                   \
     }
 #define QGX_HW_LOAD(CH, SL, V)                                                                              \
@@ -170,6 +185,11 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
     }
 
     if (n_my == 0) return;
+    int stamp_i = 0;
+    (void)stamp_i;
+    QGX_STAMP()
+    for (int i = threadIdx.x; i < 3 * COUT; i += NTHR)
+        ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
     // ---- prologue: first chunk's patch and first weight slice, synchronously
     {
         f32x4 pv[PPT];
@@ -190,9 +210,11 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
         py[mt] = p / N;
         px[mt] = p - py[mt] * N;
     }
-    // lane-dependent parts of the fragment addresses
-    const int pofs = NS == 1 ? h * 16 : h * 32;         // + j*32 (NS=1) / + j*16 (NS=2)
+    // lane-dependent parts of the fragment addresses: unit u0 (+ j*PJ bytes for fragment j)
+    const int u0 = NS == 1 ? h : 2 * h;
     constexpr int PJ = NS == 1 ? 32 : 16;
+#define QGX_HP_ADDR(PL) (SWZ ? (PL) * 64 + ((u0 ^ (((PL) >> 2) & 3)) * 16) : (PL) * 80 + u0 * 16)
+#define QGX_HP_FRAG(AOFF, J) (SWZ ? ((AOFF) ^ ((J) * PJ)) : ((AOFF) + (J) * PJ))
     const int wofs = (h * COUT + li) * 16;              // + (j*2*COUT + nt*32)*16
     f32x16 acc[MT][NT];
     int cur_w = 0;
@@ -221,6 +243,7 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
                     const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
                     QGX_HW_LOAD(wch, wsl, wv)
                 }
+                QGX_STAMP()
                 // ---- K loop over the TPS taps of this slice, fragments requested one tap ahead
                 const char *wl = wlds0 + cur_w * WSB + wofs;
                 const int tap0 = sl * TPS;
@@ -230,7 +253,7 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
                 for (int mt = 0; mt < MT; ++mt) {
                     int col = px[mt] + kx - P;
                     col = col < 0 ? col + N : (col >= N ? col - N : col);
-                    aoff[mt] = ((py[mt] + ky) * N + col) * PSTR + pofs;
+                    aoff[mt] = QGX_HP_ADDR((py[mt] + ky) * N + col);
                 }
                 h8 Pn[MT][2], Wn[NT][2];
 #pragma unroll
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + aoff[mt] + j * PJ);
+                    for (int j = 0; j < 2; ++j) Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + QGX_HP_FRAG(aoff[mt], j));
                 for (int tl = 0; tl < TPS; ++tl) {
                     const bool last_tap = tl == TPS - 1;
                     int nkx = kx + 1, nky = ky;
@@ -251,7 +274,7 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
                     for (int mt = 0; mt < MT; ++mt) {
                         int col = px[mt] + nkx - P;
                         col = col < 0 ? col + N : (col >= N ? col - N : col);
-                        aoff_n[mt] = last_tap ? aoff[mt] : ((py[mt] + nky) * N + col) * PSTR + pofs;
+                        aoff_n[mt] = last_tap ? aoff[mt] : QGX_HP_ADDR((py[mt] + nky) * N + col);
                     }
                     const char *wl_n = last_tap ? wl : wl + TAPB;
                     h8 Pc[MT][2], Wc[NT][2];
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + aoff_n[mt] + j * PJ);
+                        for (int j = 0; j < 2; ++j) Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + QGX_HP_FRAG(aoff_n[mt], j));
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
@@ -288,8 +311,19 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
                     kx = nkx; ky = nky;
                 }
 
+                QGX_STAMP()
+                // ---- retire the prefetches
+                if (sl == NSL - 1) {
+                    __syncthreads();                     // every wave is done with this chunk's patch
+                    if (have_next_chunk) QGX_HP_STORE(pv)
+                }
+                if (!last_stage) QGX_HW_STORE(wlds0 + (cur_w ^ 1) * WSB, wv)
+                __syncthreads();
+                QGX_STAMP()
+                cur_w ^= 1;
                 if (sl == NSL - 1 && ch == NCH - 1) {
-                    // ---- epilogue of this tile
+                    // ---- epilogue of this tile, AFTER the prefetches were retired: its stores then drain during the
+                    // next stage instead of being waited for (vmcnt counts loads and stores together, in order)
                     const int tile_g = blockIdx.x + ti * gridDim.x;
                     const int b = tile_g / tiles_per_img;
                     const int y0 = (tile_g - b * tiles_per_img) * R;
@@ -301,17 +335,9 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
                         char *pix = ob + (size_t)(tile * 32 + li) * OPIXB;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            store_tile_t<NS, OUTF32>(acc[mt][nt], nt * 32, h, pix, a.bias, a.scale, a.shift, a.unscale, a.ascale);
+                            store_tile_t<NS, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
                     }
                 }
-                // ---- retire the prefetches
-                if (sl == NSL - 1) {
-                    __syncthreads();                     // every wave is done with this chunk's patch
-                    if (have_next_chunk) QGX_HP_STORE(pv)
-                }
-                if (!last_stage) QGX_HW_STORE(wlds0 + (cur_w ^ 1) * WSB, wv)
-                __syncthreads();
-                cur_w ^= 1;
             }
         }
     }
@@ -319,4 +345,549 @@ __global__ __launch_bounds__(512) void k_convh(ConvHArgs a, int total_tiles) {
 #undef QGX_HP_STORE
 #undef QGX_HW_LOAD
 #undef QGX_HW_STORE
+#undef QGX_HP_ADDR
+#undef QGX_HP_FRAG
+}
+
+// ---- f16x3 hidden layers, compile-time grid size: 4 waves x 2 workgroups per CU ---------------------------
+// Same arithmetic and data layouts as k_convh<NS = 2>, built so that TWO workgroups share a CU and run
+// out of phase (one's barriers, LDS staging and operand latency under the other's MFMAs): that needs
+// <= 256 registers per wave, which the generic kernel misses because hipcc hoists its 25 x MT
+// loop-invariant per-lane tap addresses into registers.  Here the LDS patch carries a wrapped halo of
+// KS/2 columns on both sides, so a tap is a compile-time byte offset from ONE per-lane base address
+// (ds_read offset immediates, no address arithmetic, no address registers).  The weight slice is single
+// buffered where two buffers would not leave room for two workgroups (the 5x5 layer).
+template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB>
+__global__ __launch_bounds__(256, 2) void k_convh2(ConvHArgs a, int total_tiles) {
+    constexpr int NW = 4, NTHR = 256;
+    constexpr int NT = COUT / 32;
+    constexpr int P = KS / 2, T = KS * KS;
+    constexpr int NCH = CIN / 16;
+    constexpr int PIXB = CIN * 4, OPIXB = COUT * 4;
+    constexpr int N = NN, R = NW * MT * 32 / NN, PR = R + KS - 1, PW = NN + 2 * P;
+    constexpr int PSTR = 80;
+    constexpr int patch_bytes = PR * PW * PSTR;
+    constexpr int TAPB = 4 * COUT * 16, WSB = TPS * TAPB, NSL = T / TPS;
+    constexpr int PU = PR * PW * 4, PPT = (PU + NTHR - 1) / NTHR;
+    constexpr int WU = WSB / 16, WPT = (WU + NTHR - 1) / NTHR;
+    static_assert(T % TPS == 0 && (NW * MT * 32) % NN == 0 && NN % R == 0, "shape");
+    char *const lds0 = conv_smem;
+    char *const wlds0 = lds0 + patch_bytes;
+    float *const ep = reinterpret_cast<float *>(wlds0 + (WDB ? 2 : 1) * WSB);
+    const char *const inb = reinterpret_cast<const char *>(a.in);
+    const char *const wb = reinterpret_cast<const char *>(a.w);
+    constexpr int tiles_per_img = N / R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (n_my == 0) return;
+
+#define QGX_H2P_LOAD(TI, CH, V)                                                                             \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            int it_ = u * NTHR + threadIdx.x;                                                                \
+            it_ = it_ < PU ? it_ : PU - 1;                                                                  \
+            const int un_ = it_ & 3, pl_ = it_ >> 2;                                                        \
+            const int pr_ = pl_ / PW, xx_ = pl_ - pr_ * PW;                                                 \
+            int gy_ = y0_ - P + pr_, gx_ = xx_ - P;                                                         \
+            gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                           \
+            gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                           \
+            V[u] = *reinterpret_cast<const f32x4 *>(                                                        \
+                inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 64 + un_ * 16);                    \
+        }                                                                                                   \
+    }
+#define QGX_H2P_STORE(V)                                                                                    \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
+            if (it_ < PU) *reinterpret_cast<f32x4 *>(lds0 + (it_ >> 2) * PSTR + (it_ & 3) * 16) = V[u];     \
+        }                                                                                                   \
+    }
+#define QGX_H2W_LOAD(CH, SL, V)                                                                             \
+    {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(wb + ((size_t)(CH) * NSL + (SL)) * WSB);        \
+        _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
+            V[u] = src_[it_ < WU ? it_ : WU - 1];                                                           \
+        }                                                                                                   \
+    }
+#define QGX_H2W_STORE(BUF, V)                                                                               \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
+            if (it_ < WU) *reinterpret_cast<f32x4 *>((BUF) + it_ * 16) = V[u];                              \
+        }                                                                                                   \
+    }
+
+    for (int i = threadIdx.x; i < 3 * COUT; i += NTHR)
+        ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
+    {
+        f32x4 pv[PPT];
+        QGX_H2P_LOAD(0, 0, pv)
+        QGX_H2P_STORE(pv)
+        f32x4 wv[WPT];
+        QGX_H2W_LOAD(0, 0, wv)
+        QGX_H2W_STORE(wlds0, wv)
+    }
+    __syncthreads();
+
+    // ONE base address per M-tile: pixel (py, px) of the tile sits at patch row py, column px (the halo
+    // shifts the origin by -P, -P); tap (ky, kx) adds the compile-time (ky * PW + kx) * PSTR
+    int pbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = (wave + NW * mt) * 32 + li;
+        const int py = p / NN, px = p - py * NN;
+        pbase[mt] = (py * PW + px) * PSTR + h * 32;
+    }
+    const int wofs = (h * COUT + li) * 16;
+    f32x16 acc[MT][NT];
+    int cur_w = 0;
+    for (int ti = 0; ti < n_my; ++ti) {
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            }
+            const int nch = ch + 1 < NCH ? ch + 1 : 0;
+            const int nti = ch + 1 < NCH ? ti : ti + 1;
+            const bool have_next_chunk = nti < n_my;
+            f32x4 pv[PPT];
+            QGX_H2P_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch, pv)
+#pragma unroll
+            for (int sl = 0; sl < NSL; ++sl) {
+                f32x4 wv[WPT];
+                const bool last_stage = !have_next_chunk && sl == NSL - 1;
+                {
+                    const int wch = sl + 1 < NSL ? ch : (have_next_chunk ? nch : ch);
+                    const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
+                    QGX_H2W_LOAD(wch, wsl, wv)
+                }
+                const char *wl = wlds0 + (WDB ? cur_w * WSB : 0) + wofs;
+                h8 Pn[MT][2], Wn[NT][2];
+#define QGX_H2_FRAGS(TL)                                                                                    \
+                {                                                                                           \
+                    const int tap_ = sl * TPS + (TL), ky_ = tap_ / KS, kx_ = tap_ - ky_ * KS;               \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                       \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+                            Wn[nt][j] = *reinterpret_cast<const h8 *>(wl + (TL) * TAPB + (j * 2 * COUT + nt * 32) * 16); \
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                       \
+                        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
+                            Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + pbase[mt] + (ky_ * PW + kx_) * PSTR + j * 16); \
+                }
+                QGX_H2_FRAGS(0)
+#pragma unroll
+                for (int tl = 0; tl < TPS; ++tl) {
+                    h8 Pc[MT][2], Wc[NT][2];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) { Pc[mt][0] = Pn[mt][0]; Pc[mt][1] = Pn[mt][1]; }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) { Wc[nt][0] = Wn[nt][0]; Wc[nt][1] = Wn[nt][1]; }
+                    if (tl + 1 < TPS) {
+                        const int tln = tl + 1;
+                        const int tap_ = sl * TPS + tln, ky_ = tap_ / KS, kx_ = tap_ - ky_ * KS;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                Wn[nt][j] = *reinterpret_cast<const h8 *>(wl + tln * TAPB + (j * 2 * COUT + nt * 32) * 16);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + pbase[mt] + (ky_ * PW + kx_) * PSTR + j * 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[nt][1], Pc[mt][0], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[nt][0], Pc[mt][1], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[nt][0], Pc[mt][0], acc[mt][nt], 0, 0, 0);
+                        }
+                }
+#undef QGX_H2_FRAGS
+                // ---- retire the prefetches
+                if constexpr (WDB) {
+                    if (sl == NSL - 1) {
+                        __syncthreads();
+                        if (have_next_chunk) QGX_H2P_STORE(pv)
+                    }
+                    if (!last_stage) QGX_H2W_STORE(wlds0 + (cur_w ^ 1) * WSB, wv)
+                    __syncthreads();
+                    cur_w ^= 1;
+                } else {
+                    __syncthreads();                     // every wave is done with this slice (and chunk)
+                    if (!last_stage) QGX_H2W_STORE(wlds0, wv)
+                    if (sl == NSL - 1 && have_next_chunk) QGX_H2P_STORE(pv)
+                    __syncthreads();
+                }
+                if (sl == NSL - 1 && ch == NCH - 1) {
+                    const int tile_g = blockIdx.x + ti * gridDim.x;
+                    const int b = tile_g / tiles_per_img;
+                    const int y0 = (tile_g - b * tiles_per_img) * R;
+                    char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N) * OPIXB;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        char *pix = ob + (size_t)((wave + NW * mt) * 32 + li) * OPIXB;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                    }
+                }
+            }
+        }
+    }
+#undef QGX_H2P_LOAD
+#undef QGX_H2P_STORE
+#undef QGX_H2W_LOAD
+#undef QGX_H2W_STORE
+}
+
+// ---- first layer (n_in = 4 or 2 planar f32 channels -> 128, 5x5) in the f16x3 arithmetic ---------------
+// K = 25 taps x n_in channels is tiny, so the whole weight set lives in LDS (57 KB) for the lifetime of
+// the persistent workgroup; the input patch is split into hi/lo f16 while it is staged
+// ([pixel][n_in hi][n_in lo], 16 or 8 bytes per pixel).  One K = 16 MFMA step covers 4 (n_in = 4) or
+// 8 (n_in = 2) taps: lane half h takes taps TPS*s + TPF*h .. + TPF-1; tap slots beyond 25 carry zero
+// weights and re-read tap 24.  Each wave computes its MT pixel tiles against the 128 output channels
+// in two halves of 64 (accumulators 2 x MT x 16 registers).
+struct ConvHFirstArgs {
+    const float *in;       // planar (B, NIN, N, N) f32
+    void *out;             // [B][N][N][16][2][8] f16
+    const void *w;         // [step][part][h][128][8] f16
+    const float *bias, *scale, *shift;
+    float unscale, ascale;
+    int N, R;
+};
+
+template <int NIN, int MT, int PPT>
+__global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total_tiles) {
+    constexpr int KS = 5, P = 2, T = 25, COUT = 128;
+    constexpr int TPF = 8 / NIN;                 // taps per 8-element fragment
+    constexpr int TPS = 2 * TPF;                 // taps per K = 16 step
+    constexpr int NSTEP = (T + TPS - 1) / TPS;
+    constexpr int PXB = NIN * 4;                 // LDS bytes per patch pixel
+    constexpr int WBYTES = NSTEP * 4 * COUT * 16;
+    const int N = a.N, R = a.R;
+    const int PR = R + KS - 1;
+    const int patch_bytes = PR * N * PXB;
+    float *const ep = reinterpret_cast<float *>(conv_smem + WBYTES + 2 * patch_bytes);   // bias | scale | shift
+    char *const wl0 = conv_smem;
+    char *const pl0 = conv_smem + WBYTES;
+    const int tiles_per_img = N / R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int ntiles = R * N / 32;
+    const int NX4 = N / 4;
+    const int PI = PR * NIN * NX4;               // float4 items of one patch
+    if (n_my == 0) return;
+
+#define QGX_F_LOAD(TI, V)                                                                                   \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            int it_ = u * 256 + threadIdx.x;                                                                 \
+            it_ = it_ < PI ? it_ : PI - 1;                                                                  \
+            const int x4_ = it_ % NX4, c_ = (it_ / NX4) % NIN, pr_ = it_ / (NX4 * NIN);                     \
+            int gy_ = y0_ - P + pr_;                                                                        \
+            gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                           \
+            V[u] = *reinterpret_cast<const f32x4 *>(&a.in[(((size_t)b_ * NIN + c_) * N + gy_) * N + x4_ * 4]); \
+        }                                                                                                   \
+    }
+#define QGX_F_STORE(BUF, V)                                                                                 \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            const int it_ = u * 256 + threadIdx.x;                                                           \
+            if (it_ < PI) {                                                                                 \
+                const int x4_ = it_ % NX4, c_ = (it_ / NX4) % NIN, pr_ = it_ / (NX4 * NIN);                 \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
+                    const float x_ = V[u][e];                                                               \
+                    const _Float16 xh_ = (_Float16)x_;                                                      \
+                    _Float16 *px_ = reinterpret_cast<_Float16 *>((BUF) + (pr_ * N + x4_ * 4 + e) * PXB);    \
+                    px_[c_] = xh_;                                                                          \
+                    px_[NIN + c_] = (_Float16)(x_ - (float)xh_);                                            \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    for (int i = threadIdx.x; i < 3 * COUT; i += 256)
+        ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
+    // ---- prologue: weights (once) and the first patch
+    for (int it = threadIdx.x; it < WBYTES / 16; it += 256)
+        reinterpret_cast<f32x4 *>(wl0)[it] = reinterpret_cast<const f32x4 *>(a.w)[it];
+    {
+        f32x4 pv[PPT];
+        QGX_F_LOAD(0, pv)
+        QGX_F_STORE(pl0, pv)
+    }
+    __syncthreads();
+
+    int py[MT], px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int tile = wave + 4 * mt;
+        if (tile >= ntiles) tile = wave % ntiles;
+        const int p = tile * 32 + li;
+        py[mt] = p / N;
+        px[mt] = p - py[mt] * N;
+    }
+    int cur = 0;
+    for (int ti = 0; ti < n_my; ++ti) {
+        const bool have_next = ti + 1 < n_my;
+        f32x4 pv[PPT];
+        QGX_F_LOAD(have_next ? ti + 1 : ti, pv)
+        const char *pl = pl0 + cur * patch_bytes;
+        const int tile_g = blockIdx.x + ti * gridDim.x;
+        const int b = tile_g / tiles_per_img;
+        const int y0 = (tile_g - b * tiles_per_img) * R;
+        char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N) * (COUT * 4);
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            f32x16 acc[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            const char *wl = wl0 + (h * COUT + half * 64 + li) * 16;
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                h8 W[2][2];     // [nt][part]
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int part = 0; part < 2; ++part)
+                        W[nt][part] = *reinterpret_cast<const h8 *>(wl + ((s * 2 + part) * 2 * COUT + nt * 32) * 16);
+                h8 Ph[MT], Pl[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    unsigned hw[4], lw[4];
+#pragma unroll
+                    for (int f = 0; f < TPF; ++f) {
+                        int tap = TPS * s + TPF * h + f;
+                        tap = tap < T ? tap : T - 1;
+                        const int ky = tap / KS, kx = tap - ky * KS;
+                        int col = px[mt] + kx - P;
+                        col = col < 0 ? col + N : (col >= N ? col - N : col);
+                        const char *src = pl + ((py[mt] + ky) * N + col) * PXB;
+                        if constexpr (NIN == 4) {
+                            const u32x4 v = *reinterpret_cast<const u32x4 *>(src);
+                            hw[2 * f] = v[0]; hw[2 * f + 1] = v[1]; lw[2 * f] = v[2]; lw[2 * f + 1] = v[3];
+                        } else {
+                            const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                            hw[f] = v.x; lw[f] = v.y;
+                        }
+                    }
+                    const u32x4 hv = {hw[0], hw[1], hw[2], hw[3]}, lv = {lw[0], lw[1], lw[2], lw[3]};
+                    Ph[mt] = __builtin_bit_cast(h8, hv);
+                    Pl[mt] = __builtin_bit_cast(h8, lv);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], Ph[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Pl[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Ph[mt], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+            // the next patch goes to LDS before this tile's first output store is issued: waiting for its
+            // loads later would also wait for those stores (one in-order counter)
+            if (half == 0 && have_next) QGX_F_STORE(pl0 + (cur ^ 1) * patch_bytes, pv)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int tile = wave + 4 * mt;
+                if (tile >= ntiles) continue;
+                char *pix = ob + (size_t)(tile * 32 + li) * (COUT * 4);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    store_tile_t<2, false>(acc[mt][nt], half * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#undef QGX_F_LOAD
+#undef QGX_F_STORE
+}
+
+// ---- 3x3 hidden layers with RESIDENT weights (f16x3) ------------------------------------------------------
+// The 3x3 layers are small (<= 73.7 KB of hi/lo weights), so a persistent 8-wave workgroup keeps the
+// whole weight set in LDS and stages only the input patch: 32 channels (128 bytes: 4 octets x hi/lo) per
+// pixel and chunk, unit index XOR-swizzled by bits 1..3 of the pixel index (conflict-free
+// ds_read_b128 at a 128-byte pixel stride).  The next chunk's / tile's patch is fetched into registers
+// at the start of a chunk, i.e. a whole 32-channel chunk (~3.5 us) ahead of its use, which is what the
+// 16-channel kernel above lacked on these memory-latency-bound layers; two barriers per chunk.
+template <int CIN, int COUT, int MT, int PPT, bool OUTF32>
+__global__ __launch_bounds__(512) void k_convh_res(ConvHArgs a, int total_tiles) {
+    constexpr int NW = 8, NTHR = 512, KS = 3, P = 1, T = 9;
+    constexpr int NT = COUT / 32;
+    constexpr int NCH = CIN / 32;
+    constexpr int PIXB = CIN * 4;
+    constexpr int OPIXB = OUTF32 ? COUT * 4 : COUT * 4;
+    constexpr int WBYTES = (CIN / 16) * T * 4 * COUT * 16;
+    const int N = a.N, R = a.R;
+    const int PR = R + KS - 1;
+    const int PU = PR * N * 8;                          // 16-byte units of one patch chunk
+    char *const wl0 = conv_smem;
+    char *const lds0 = conv_smem + WBYTES;
+    float *const ep = reinterpret_cast<float *>(lds0 + PR * N * 128);   // bias | scale | shift
+    const char *const inb = reinterpret_cast<const char *>(a.in);
+    const int tiles_per_img = N / R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int ntiles = R * N / 32;
+    if (n_my == 0) return;
+    int stamp_i = 0;
+    (void)stamp_i;
+    QGX_STAMP()
+
+#define QGX_RP_LOAD(TI, CH, V)                                                                              \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            int it_ = u * NTHR + threadIdx.x;                                                                \
+            it_ = it_ < PU ? it_ : PU - 1;                                                                  \
+            const int un_ = it_ & 7, pl_ = it_ >> 3;                                                        \
+            const int pr_ = pl_ / N, x_ = pl_ - pr_ * N;                                                    \
+            int gy_ = y0_ - P + pr_;                                                                        \
+            gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                           \
+            V[u] = *reinterpret_cast<const f32x4 *>(                                                        \
+                inb + (((size_t)b_ * N + gy_) * N + x_) * PIXB + (CH) * 128 + un_ * 16);                    \
+        }                                                                                                   \
+    }
+#define QGX_RP_STORE(V)                                                                                     \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
+            if (it_ < PU)                                                                                   \
+                *reinterpret_cast<f32x4 *>(lds0 + (it_ >> 3) * 128 + (((it_ & 7) ^ ((it_ >> 4) & 7)) * 16)) = V[u]; \
+        }                                                                                                   \
+    }
+
+    for (int i = threadIdx.x; i < 3 * COUT; i += NTHR)
+        ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
+    // ---- prologue: the whole weight set (once) and the first patch chunk
+    for (int it = threadIdx.x; it < WBYTES / 16; it += NTHR)
+        reinterpret_cast<f32x4 *>(wl0)[it] = reinterpret_cast<const f32x4 *>(a.w)[it];
+    {
+        f32x4 pv[PPT];
+        QGX_RP_LOAD(0, 0, pv)
+        QGX_RP_STORE(pv)
+    }
+    __syncthreads();
+    QGX_STAMP()
+
+    int py[MT], px[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int tile = wave + NW * mt;
+        if (tile >= ntiles) tile = wave % ntiles;
+        const int p = tile * 32 + li;
+        py[mt] = p / N;
+        px[mt] = p - py[mt] * N;
+    }
+    const char *const wlane = wl0 + (h * COUT + li) * 16;
+    f32x16 acc[MT][NT];
+    for (int ti = 0; ti < n_my; ++ti) {
+        for (int ch = 0; ch < NCH; ++ch) {
+            if (ch == 0) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            }
+            const int nch = ch + 1 < NCH ? ch + 1 : 0;
+            const int nti = ch + 1 < NCH ? ti : ti + 1;
+            const bool have_next = nti < n_my;
+            f32x4 pv[PPT];
+            QGX_RP_LOAD(have_next ? nti : ti, have_next ? nch : ch, pv)
+
+            // ---- K loop: 9 taps x 2 K=16 steps (octet pairs 0-1 / 2-3 of the chunk), one step ahead
+            // fragment address of step s = 2 tap + t: hi at base[tap] ^ (t * 64), lo at hi ^ 16
+            h8 Pn[MT][2], Wn[NT][2];
+#define QGX_RP_FRAGS(S)                                                                                     \
+            {                                                                                               \
+                constexpr int tap_ = (S) >> 1, t_ = (S) & 1, ky_ = tap_ / 3, kx_ = tap_ - 3 * ky_;          \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                         \
+                    int col = px[mt] + kx_ - P;                                                             \
+                    col = col < 0 ? col + N : (col >= N ? col - N : col);                                   \
+                    const int pl_ = (py[mt] + ky_) * N + col;                                               \
+                    const int hi_ = pl_ * 128 + ((((2 * h) ^ ((pl_ >> 1) & 7)) * 16) ^ (t_ * 64));          \
+                    Pn[mt][0] = *reinterpret_cast<const h8 *>(lds0 + hi_);                                  \
+                    Pn[mt][1] = *reinterpret_cast<const h8 *>(lds0 + (hi_ ^ 16));                           \
+                }                                                                                           \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                           \
+                    _Pragma("unroll") for (int part = 0; part < 2; ++part)                                  \
+                        Wn[nt][part] = *reinterpret_cast<const h8 *>(                                       \
+                            wlane + ((size_t)(((ch * 2 + t_) * T + tap_) * 4 + part * 2) * COUT + nt * 32) * 16); \
+            }
+            QGX_STAMP()
+            QGX_RP_FRAGS(0)
+#define QGX_RP_STEP(S)                                                                                      \
+            {                                                                                               \
+                h8 Pc[MT][2], Wc[NT][2];                                                                    \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) { Pc[mt][0] = Pn[mt][0]; Pc[mt][1] = Pn[mt][1]; } \
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { Wc[nt][0] = Wn[nt][0]; Wc[nt][1] = Wn[nt][1]; } \
+                if constexpr ((S) + 1 < 2 * T) QGX_RP_FRAGS((S) + 1)                                        \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+                _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                           \
+                    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) {                                     \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[nt][1], Pc[mt][0], acc[mt][nt], 0, 0, 0); \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[nt][0], Pc[mt][1], acc[mt][nt], 0, 0, 0); \
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[nt][0], Pc[mt][0], acc[mt][nt], 0, 0, 0); \
+                    }                                                                                       \
+            }
+            QGX_RP_STEP(0) QGX_RP_STEP(1) QGX_RP_STEP(2) QGX_RP_STEP(3) QGX_RP_STEP(4) QGX_RP_STEP(5)
+            QGX_RP_STEP(6) QGX_RP_STEP(7) QGX_RP_STEP(8) QGX_RP_STEP(9) QGX_RP_STEP(10) QGX_RP_STEP(11)
+            QGX_RP_STEP(12) QGX_RP_STEP(13) QGX_RP_STEP(14) QGX_RP_STEP(15) QGX_RP_STEP(16) QGX_RP_STEP(17)
+#undef QGX_RP_STEP
+#undef QGX_RP_FRAGS
+            QGX_STAMP()
+
+            QGX_STAMP()
+            __syncthreads();                             // every wave is done with this chunk's patch
+            QGX_STAMP()
+            if (have_next) QGX_RP_STORE(pv)
+            QGX_STAMP()
+            __syncthreads();
+            // epilogue AFTER the prefetch was retired: its stores drain during the next chunk's K loop
+            if (ch == NCH - 1) {
+                const int tile_g = blockIdx.x + ti * gridDim.x;
+                const int b = tile_g / tiles_per_img;
+                const int y0 = (tile_g - b * tiles_per_img) * R;
+                char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N) * OPIXB;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int tile = wave + NW * mt;
+                    if (tile >= ntiles) continue;
+                    char *pix = ob + (size_t)(tile * 32 + li) * OPIXB;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                }
+            }
+            QGX_STAMP()
+        }
+    }
+#undef QGX_RP_LOAD
+#undef QGX_RP_STORE
 }
