@@ -711,7 +711,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
-    int opt_h2 = 2;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
+    int opt_h2 = 3;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
     int opt_res = 1;               // f16x3 3x3 layers: resident-weight kernel where its tile fits in LDS
     int opt_member_chunk = 0;      // 16-bit path: members per sub-batch (0 = whole ensemble)
     int opt_half_nw = 8;           // 16-bit hidden layers: 4 waves x 2 workgroups per CU, or 8 x 1
@@ -1140,33 +1140,46 @@ static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const v
 static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *in, float *out, int B, int N,
                             int n_out, hipStream_t st);
 
-// f16x3 hidden layers at the grid sizes with a compile-time specialisation (k_convh2, 2 workgroups per CU)
-template <int CIN, int COUT, int KS, bool OUTF32>
-static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
-                         hipStream_t st, bool &done) {
-    done = false;
-    if (N != 64) return QGX_OK;
-    constexpr int NN = 64, MT = 2, TPS = KS == 5 ? 5 : 9;
-    constexpr bool WDB = KS == 3;
+// f16x3 hidden layers at the grid sizes with a compile-time specialisation (k_convh2; 2 workgroups per CU
+// where the LDS budget allows)
+template <int CIN, int COUT, int KS, bool OUTF32, int NN, int MT>
+static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B,
+                           hipStream_t st) {
+    constexpr int TPS = KS == 5 ? 5 : 9;
     constexpr int R = 4 * MT * 32 / NN, PR = R + KS - 1, PW = NN + 2 * (KS / 2);
+    constexpr bool WDB = KS == 3;                                // double-buffered weight slice (3x3 layers)
     constexpr size_t lds = (size_t)PR * PW * 80 + (size_t)(WDB ? 2 : 1) * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
-    static_assert(lds * 2 <= 160 * 1024, "two workgroups per CU");
+    static_assert(lds <= 160 * 1024, "LDS");
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
-    a.N = N; a.R = R;
-    const int total_tiles = B * (N / R);
-    int grid = 512;
+    a.N = NN; a.R = R;
+    const int total_tiles = B * (NN / R);
+    int grid = lds * 2 <= 160 * 1024 ? 512 : 256;
     if (grid > total_tiles) grid = total_tiles;
-    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB>;
+    constexpr bool TWO = lds * 2 <= 160 * 1024 && MT == 2;        // two workgroups per CU: <= 256 registers
+    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO>;
     QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
-    done = true;
     return QGX_OK;
+}
+
+template <int CIN, int COUT, int KS, bool OUTF32>
+static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                         hipStream_t st, bool &done) {
+    done = true;
+    switch (N) {
+        case 32: return launch_convh2_n<CIN, COUT, KS, OUTF32, 32, 2>(g, layer, L, in, out, B, st);
+        case 48: return launch_convh2_n<CIN, COUT, KS, OUTF32, 48, 3>(g, layer, L, in, out, B, st);
+        case 64: return launch_convh2_n<CIN, COUT, KS, OUTF32, 64, 2>(g, layer, L, in, out, B, st);
+        case 96: return launch_convh2_n<CIN, COUT, KS, OUTF32, 96, 3>(g, layer, L, in, out, B, st);
+        case 128: return launch_convh2_n<CIN, COUT, KS, OUTF32, 128, 2>(g, layer, L, in, out, B, st);
+        default: done = false; return QGX_OK;
+    }
 }
 
 // 3x3 layers, f16x3, resident weights (k_convh_res); done = false when the tile does not fit in LDS
