@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "philox.hpp"
 #include <cmath>
+#include <utility>
 #include <new>
 
 namespace qgx {
@@ -41,6 +42,7 @@ struct ConvArgs {
 extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
 #include "conv_half.hpp"
+#include "conv_pair.hpp"
 
 // OUTH = 0: f32 NHWC output.  OUTH = 1 / 2 (first layer only): the MFMA roles are swapped (lane = pixel)
 // and the epilogue writes the packed f16 / f16 hi-lo activation layout of conv_half.hpp.
@@ -711,6 +713,8 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_fuse = 2;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
+    int opt_pair = 1;              // 3x3 k_convh2: fetch both 64-byte halves of a pixel's 128-byte line together
     int opt_h2 = 3;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
     int opt_res = 1;               // f16x3 3x3 layers: resident-weight kernel where its tile fits in LDS
     int opt_member_chunk = 0;      // 16-bit path: members per sub-batch (0 = whole ensemble)
@@ -763,6 +767,7 @@ static int pack_weights(const LayerHost &L, int li, const qgx_cnn_weights *w, bo
 // conv_half.hpp weight layout [chunk][tap][j][h][cout][8] f16, pre-scaled by 2^s with max|w| 2^s in [2^13, 2^14)
 static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
     const int cin = L.cin, cout = L.cout, T = L.ks * L.ks;
+    const int coutp = ((cout + 31) / 32) * 32;         // the 32 -> 2 last layer is padded with zero rows
     const int CC = NS == 1 ? 32 : 16, nch = cin / CC;
     const float *W = w->conv_w[li];
     float mx = 0.f;
@@ -772,7 +777,7 @@ static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
     int sexp = 14 - e;
     sexp = sexp < -20 ? -20 : (sexp > 40 ? 40 : sexp);
     const float sc = ldexpf(1.f, sexp);
-    std::vector<_Float16> pw((size_t)nch * T * 4 * cout * 8, (_Float16)0.f);
+    std::vector<_Float16> pw((size_t)nch * T * 4 * coutp * 8, (_Float16)0.f);
     for (int ch = 0; ch < nch; ++ch)
         for (int t = 0; t < T; ++t)
             for (int j = 0; j < 2; ++j)
@@ -783,7 +788,7 @@ static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
                             const float x = W[((size_t)co * cin + c) * T + t] * sc;
                             const _Float16 xh = (_Float16)x;
                             const _Float16 v = (NS == 1 || j == 0) ? xh : (_Float16)(x - (float)xh);
-                            pw[(((((size_t)ch * T + t) * 2 + j) * 2 + hh) * cout + co) * 8 + e8] = v;
+                            pw[(((((size_t)ch * T + t) * 2 + j) * 2 + hh) * coutp + co) * 8 + e8] = v;
                         }
     void *&dst = L.wh[NS - 1];
     QGX_HIP(hipMalloc(&dst, pw.size() * sizeof(_Float16)));
@@ -850,7 +855,7 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
         }
         if (li < 7) {
             if ((rc = pack_half(L, li, w, 1)) || (rc = pack_half(L, li, w, 2))) return rc;
-        }
+        } else if ((rc = pack_half(L, li, w, 2))) return rc;      // fused (layer 7, layer 8) pair
     }
     if (li == 7) {      // [tap][c][2] for the VALU last-layer kernel
         const int cin = L.cin, ks = L.ks;
@@ -1160,7 +1165,8 @@ static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, cons
     int grid = lds * 2 <= 160 * 1024 ? 512 : 256;
     if (grid > total_tiles) grid = total_tiles;
     constexpr bool TWO = lds * 2 <= 160 * 1024 && MT == 2;        // two workgroups per CU: <= 256 registers
-    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO>;
+    auto kern = g->opt_pair && KS == 3 ? k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO, KS == 3>
+                                        : k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO, false>;
     QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
@@ -1234,6 +1240,35 @@ static int conv3x3_half(qgx_generator *g, int layer, const LayerHost &L, const v
     return launch_convh<CIN, COUT, 3, NS, OUTF32>(g, layer, L, in, out, B, N, st);
 }
 
+// two fused 3x3 layers (k_convh_pair); 64 x 64 grids
+template <int CINA, bool LAST, bool BOUTF32>
+static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, const LayerHost &LB, const void *in,
+                             void *out, int B, int N, int n_out, hipStream_t st) {
+    constexpr int NN = 64, R = 8, PW = NN + 2;
+    QGX_REQUIRE(N == NN, "generator: fused layer pairs need N=%d", NN);
+    constexpr size_t reg0 = (size_t)(R + 2) * PW * 144 > (size_t)(R + 4) * PW * 80 ? (size_t)(R + 2) * PW * 144 : (size_t)(R + 4) * PW * 80;
+    constexpr size_t lds = reg0 + 3 * (9 * 4 * 32 * 16) + 2 * 96 * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS");
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layerA, st, prof_stop); if (prc) return prc; }
+    ConvPairArgs a = {};
+    a.in = in; a.out = out; a.wA = LA.wh[1]; a.wB = LB.wh[1];
+    a.biasA = LA.bias; a.scaleA = LA.scale; a.shiftA = LA.shift;
+    a.biasB = LB.bias; a.scaleB = LB.scale; a.shiftB = LB.shift;
+    a.unscaleA = LA.wh_unscale[1] / g->opt_ascale; a.unscaleB = LB.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
+    a.n_out = n_out;
+    a.stamps = layerA == g->stamp_layer ? g->stamps : nullptr;
+    const int total_tiles = B * (N / R);
+    int grid = 256;
+    if (grid > total_tiles) grid = total_tiles;
+    auto kern = k_convh_pair<CINA, NN, LAST, BOUTF32>;
+    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
+}
+
 template <int NIN>
 static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float *in, void *out, int B, int N,
                               hipStream_t st) {
@@ -1288,6 +1323,32 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         bool done1 = false;
         if (NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, net.L[1], A, Bb, Bc, N, st))) return rc;
+        if (NS == 2 && g->opt_fuse && N == 64 && net.n_out <= 2) {
+            // 3x3 layers fused pairwise (the intermediate activation stays in LDS); "fuse" bits: 1 = layers
+            // (5, 6), 2 = layers (7, 8), 4 = layers (3, 4) — the 64-channel pair measured slower fused
+            if (g->opt_fuse & 4) {
+                if ((rc = launch_convh_pair<64, false, false>(g, 2, net.L[2], net.L[3], Bb, A, Bc, N, 0, st))) return rc;
+            } else {
+                if ((rc = conv3x3_half<64, 32, NS, false>(g, 2, net.L[2], Bb, A, Bc, N, st))) return rc;
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 3, net.L[3], A, Bb, Bc, N, st))) return rc;
+            }
+            // here the activation is in A (fused pair) or Bb (two kernels)
+            float *cur = (g->opt_fuse & 4) ? A : Bb, *oth = (g->opt_fuse & 4) ? Bb : A;
+            if (g->opt_fuse & 1) {
+                if ((rc = launch_convh_pair<32, false, false>(g, 4, net.L[4], net.L[5], cur, oth, Bc, N, 0, st))) return rc;
+                std::swap(cur, oth);
+            } else {
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], cur, oth, Bc, N, st))) return rc;
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 5, net.L[5], oth, cur, Bc, N, st))) return rc;
+            }
+            if (g->opt_fuse & 2) {
+                if ((rc = launch_convh_pair<32, true, false>(g, 6, net.L[6], net.L[7], cur, yc, Bc, N, net.n_out, st))) return rc;
+            } else {
+                if ((rc = conv3x3_half<32, 32, NS, true>(g, 6, net.L[6], cur, oth, Bc, N, st))) return rc;
+                if ((rc = launch_conv_last(g, net.L[7], oth, yc, Bc, N, net.n_out, st))) return rc;
+            }
+            continue;
+        }
         if ((rc = conv3x3_half<64, 32, NS, false>(g, 2, net.L[2], Bb, A, Bc, N, st))) return rc;
         if ((rc = conv3x3_half<32, 32, NS, false>(g, 3, net.L[3], A, Bb, Bc, N, st))) return rc;
         if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], Bb, A, Bc, N, st))) return rc;
@@ -1474,6 +1535,8 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "member_chunk")) { QGX_REQUIRE(value >= 0, "member_chunk must be >= 0"); g->opt_member_chunk = value; }
     else if (!strcmp(name, "res")) g->opt_res = value ? 1 : 0;
     else if (!strcmp(name, "h2")) g->opt_h2 = value & 3;
+    else if (!strcmp(name, "pair")) g->opt_pair = value ? 1 : 0;
+    else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
     else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= 0 && value <= 12, "ascale_log2 must be in 0..12"); g->opt_ascale = ldexpf(1.f, value); }

@@ -51,6 +51,19 @@ struct ConvHArgs {
 #define QGX_STAMP()
 #endif
 
+// prologue copies global -> LDS through registers: ALL loads are issued before the first store, so a
+// prologue pays one memory latency instead of one per loop iteration
+#define QGX_BULK_LOAD(V, SRC, NUNITS, NTHR_)                                                                \
+    _Pragma("unroll") for (int u = 0; u < ((NUNITS) + (NTHR_) - 1) / (NTHR_); ++u) {                        \
+        const int it_ = u * (NTHR_) + threadIdx.x;                                                           \
+        V[u] = reinterpret_cast<const f32x4 *>(SRC)[it_ < (NUNITS) ? it_ : (NUNITS) - 1];                   \
+    }
+#define QGX_BULK_STORE(V, DST, NUNITS, NTHR_)                                                               \
+    _Pragma("unroll") for (int u = 0; u < ((NUNITS) + (NTHR_) - 1) / (NTHR_); ++u) {                        \
+        const int it_ = u * (NTHR_) + threadIdx.x;                                                           \
+        if (it_ < (NUNITS)) reinterpret_cast<f32x4 *>(DST)[it_] = V[u];                                     \
+    }
+
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
     h2 v = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, v);
@@ -357,7 +370,7 @@ __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles)
 // KS/2 columns on both sides, so a tap is a compile-time byte offset from ONE per-lane base address
 // (ds_read offset immediates, no address arithmetic, no address registers).  The weight slice is single
 // buffered where two buffers would not leave room for two workgroups (the 5x5 layer).
-template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB, bool TWO>
+template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB, bool TWO, bool PAIR = false>
 __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int total_tiles) {
     constexpr int NW = 4, NTHR = 256;
     constexpr int NT = COUT / 32;
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
     constexpr int PU = PR * PW * 4, PPT = (PU + NTHR - 1) / NTHR;
     constexpr int WU = WSB / 16, WPT = (WU + NTHR - 1) / NTHR;
     static_assert(T % TPS == 0 && (NW * MT * 32) % NN == 0 && NN % R == 0, "shape");
+    static_assert(!PAIR || (NCH % 2 == 0 && NSL == 1), "line-pair prefetch: even chunk count, one slice per chunk");
     char *const lds0 = conv_smem;
     char *const wlds0 = lds0 + patch_bytes;
     float *const ep = reinterpret_cast<float *>(wlds0 + (WDB ? 2 : 1) * WSB);
@@ -424,10 +438,21 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
 
     for (int i = threadIdx.x; i < 3 * COUT; i += NTHR)
         ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
+    // PAIR: a pixel's two consecutive 16-channel chunks are the two halves of one 128-byte line; fetching them
+    // in different chunk iterations re-fetched the line from HBM (FETCH_SIZE 1.3-1.8x the algorithmic
+    // bytes on these bandwidth-bound layers), so both halves are loaded together, one chunk PAIR ahead, and
+    // the odd half waits in registers for its turn
+    f32x4 pvA[PAIR ? PPT : 1], pvB[PAIR ? PPT : 1];
     {
-        f32x4 pv[PPT];
-        QGX_H2P_LOAD(0, 0, pv)
-        QGX_H2P_STORE(pv)
+        if constexpr (PAIR) {
+            QGX_H2P_LOAD(0, 0, pvA)
+            QGX_H2P_LOAD(0, 1, pvB)
+            QGX_H2P_STORE(pvA)
+        } else {
+            f32x4 pv[PPT];
+            QGX_H2P_LOAD(0, 0, pv)
+            QGX_H2P_STORE(pv)
+        }
         f32x4 wv[WPT];
         QGX_H2W_LOAD(0, 0, wv)
         QGX_H2W_STORE(wlds0, wv)
@@ -447,6 +472,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
     f32x16 acc[MT][NT];
     int cur_w = 0;
     for (int ti = 0; ti < n_my; ++ti) {
+#pragma unroll(PAIR ? NCH : 1)
         for (int ch = 0; ch < NCH; ++ch) {
             if (ch == 0) {
 #pragma unroll
@@ -459,8 +485,15 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
             const int nch = ch + 1 < NCH ? ch + 1 : 0;
             const int nti = ch + 1 < NCH ? ti : ti + 1;
             const bool have_next_chunk = nti < n_my;
-            f32x4 pv[PPT];
-            QGX_H2P_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch, pv)
+            f32x4 pv[PAIR ? 1 : PPT];
+            if constexpr (PAIR) {
+                if (ch & 1) {                           // the next pair (nch is even), possibly of the next tile
+                    QGX_H2P_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch - 1, pvA)
+                    QGX_H2P_LOAD(have_next_chunk ? nti : ti, (have_next_chunk ? nch : ch - 1) + 1, pvB)
+                }
+            } else {
+                QGX_H2P_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch, pv)
+            }
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) {
                 f32x4 wv[WPT];
@@ -519,7 +552,11 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                 if constexpr (WDB) {
                     if (sl == NSL - 1) {
                         __syncthreads();
-                        if (have_next_chunk) QGX_H2P_STORE(pv)
+                        if constexpr (PAIR) {
+                            if (ch & 1) { if (have_next_chunk) QGX_H2P_STORE(pvA) } else QGX_H2P_STORE(pvB)
+                        } else {
+                            if (have_next_chunk) QGX_H2P_STORE(pv)
+                        }
                     }
                     if (!last_stage) QGX_H2W_STORE(wlds0 + (cur_w ^ 1) * WSB, wv)
                     __syncthreads();
@@ -527,7 +564,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                 } else {
                     __syncthreads();                     // every wave is done with this slice (and chunk)
                     if (!last_stage) QGX_H2W_STORE(wlds0, wv)
-                    if (sl == NSL - 1 && have_next_chunk) QGX_H2P_STORE(pv)
+                    if constexpr (!PAIR) { if (sl == NSL - 1 && have_next_chunk) QGX_H2P_STORE(pv) }
                     __syncthreads();
                 }
                 if (sl == NSL - 1 && ch == NCH - 1) {
@@ -625,12 +662,12 @@ __global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total
     for (int i = threadIdx.x; i < 3 * COUT; i += 256)
         ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
     // ---- prologue: weights (once) and the first patch
-    for (int it = threadIdx.x; it < WBYTES / 16; it += 256)
-        reinterpret_cast<f32x4 *>(wl0)[it] = reinterpret_cast<const f32x4 *>(a.w)[it];
     {
-        f32x4 pv[PPT];
+        f32x4 pv[PPT], wtmp[(WBYTES / 16 + 255) / 256];
         QGX_F_LOAD(0, pv)
+        QGX_BULK_LOAD(wtmp, a.w, WBYTES / 16, 256)
         QGX_F_STORE(pl0, pv)
+        QGX_BULK_STORE(wtmp, wl0, WBYTES / 16, 256)
     }
     __syncthreads();
 
@@ -784,12 +821,12 @@ __global__ __launch_bounds__(512) void k_convh_res(ConvHArgs a, int total_tiles)
     for (int i = threadIdx.x; i < 3 * COUT; i += NTHR)
         ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
     // ---- prologue: the whole weight set (once) and the first patch chunk
-    for (int it = threadIdx.x; it < WBYTES / 16; it += NTHR)
-        reinterpret_cast<f32x4 *>(wl0)[it] = reinterpret_cast<const f32x4 *>(a.w)[it];
     {
-        f32x4 pv[PPT];
+        f32x4 pv[PPT], wtmp[(WBYTES / 16 + NTHR - 1) / NTHR];
         QGX_RP_LOAD(0, 0, pv)
+        QGX_BULK_LOAD(wtmp, a.w, WBYTES / 16, NTHR)
         QGX_RP_STORE(pv)
+        QGX_BULK_STORE(wtmp, wl0, WBYTES / 16, NTHR)
     }
     __syncthreads();
     QGX_STAMP()

@@ -1,0 +1,317 @@
+// Two consecutive 3x3 layers in one kernel (f16x3 arithmetic), the intermediate activation never
+// leaves LDS.  Included by conv.hip after conv_half.hpp.
+//
+// Why: the 3x3 layers of the generator move 128 bytes per pixel in and out for 9-18 kFLOP per pixel
+// and run at the HBM roofline (profiles/: 4.3-5.2 TB/s); the only way to make them faster is to move
+// fewer bytes.  Fusing layer A (CINA -> 32) with layer B (32 -> 32, or the final 32 -> 2) removes A's
+// output write and B's halo-amplified read: a pair reads (R+4)/R of A's input once and writes B's
+// output once.  Cost: layer A is evaluated on R+2 rows per R output rows (recompute 1.25x at R = 8).
+//
+// One persistent 8-wave workgroup per CU owns R = 8 full-width rows of B's output:
+//   phase A  rows y0-1 .. y0+R of layer A (20 M-tiles of 32 pixels, 3 slots per wave, waves 4-7 use 2)
+//            from the (R+4)-row input patch, staged per 16-channel chunk (80-byte pixels, wrapped
+//            x-halo -> compile-time tap offsets), weight slice of the chunk single-buffered;
+//            epilogue (bias, ReLU, BatchNorm, hi/lo split) writes the (R+2)-row intermediate patch into
+//            the SAME LDS region (144-byte pixels: 4 octets x hi/lo, x-halo duplicated), which the input
+//            chunk no longer needs
+//   phase B  R rows of layer B from the intermediate patch against layer B's weights, which stay
+//            resident in LDS for the lifetime of the workgroup.
+// Global prefetch into registers: next input chunk / weight slice during a chunk's K loop; the next
+// tile's first chunk during phase B.  Output stores are issued after the prefetches were retired.
+#pragma once
+
+struct ConvPairArgs {
+    const void *in;        // [B][N][N][CINA/8][2][8] f16
+    void *out;             // [B][N][N][4][2][8] f16, or (LAST) planar f32 (B, n_out, N, N)
+    const void *wA, *wB;   // [chunk16][tap][part][h][32][8] f16
+    const float *biasA, *scaleA, *shiftA, *biasB, *scaleB, *shiftB;
+    float unscaleA, unscaleB, ascale;
+    int n_out;             // LAST: number of real output channels (<= 2)
+    unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only
+};
+
+template <int CINA, int NN, bool LAST, bool BOUTF32>
+__global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_tiles) {
+    constexpr int NW = 8, NTHR = 512, N = NN, R = 8, T = 9;
+    constexpr int NCA = CINA / 16;
+    constexpr int PIXB = CINA * 4;
+    constexpr int PW = NN + 2;
+    constexpr int RA = R + 2, RI = R + 4;                // rows of the intermediate / input patches
+    constexpr int ASTR = 80, MSTR = 144;
+    constexpr int REG0 = RA * PW * MSTR > RI * PW * ASTR ? RA * PW * MSTR : RI * PW * ASTR;
+    constexpr int WSLICE = T * 4 * 32 * 16;              // one 16-channel chunk of a 3x3 x 32 layer
+    constexpr int WB_BYTES = 2 * WSLICE;
+    constexpr int NTA = RA * NN / 32;                    // M-tiles of phase A (20 at 64 x 64)
+    constexpr int MTA = (NTA + NW - 1) / NW, MTB = R * NN / 32 / NW;
+    constexpr int PU = RI * PW * 4, PPT = (PU + NTHR - 1) / NTHR;
+    constexpr int WU = WSLICE / 16, WPT = (WU + NTHR - 1) / NTHR;
+    static_assert(R * NN / 32 % NW == 0 && NN % R == 0, "shape");
+    char *const reg0 = conv_smem;
+    char *const wB = conv_smem + REG0;
+    char *const wA = wB + WB_BYTES;
+    float *const epA = reinterpret_cast<float *>(wA + WSLICE);
+    float *const epB = epA + 96;
+    const char *const inb = reinterpret_cast<const char *>(a.in);
+    constexpr int tiles_per_img = N / R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    if (n_my == 0) return;
+    int stamp_i = 0;
+    (void)stamp_i;
+    QGX_STAMP()
+
+#define QGX_PP_LOAD(TI, CH, V)                                                                              \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            int it_ = u * NTHR + threadIdx.x;                                                                \
+            it_ = it_ < PU ? it_ : PU - 1;                                                                  \
+            const int un_ = it_ & 3, pl_ = it_ >> 2;                                                        \
+            const int pr_ = pl_ / PW, xx_ = pl_ - pr_ * PW;                                                 \
+            int gy_ = y0_ - 2 + pr_, gx_ = xx_ - 1;                                                         \
+            gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                           \
+            gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                           \
+            V[u] = *reinterpret_cast<const f32x4 *>(                                                        \
+                inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 64 + un_ * 16);                    \
+        }                                                                                                   \
+    }
+#define QGX_PP_STORE(V)                                                                                     \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
+            if (it_ < PU) *reinterpret_cast<f32x4 *>(reg0 + (it_ >> 2) * ASTR + (it_ & 3) * 16) = V[u];     \
+        }                                                                                                   \
+    }
+#define QGX_PW_LOAD(CH, V)                                                                                  \
+    {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(a.wA) + (size_t)(CH) * WSLICE); \
+        _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
+            V[u] = src_[it_ < WU ? it_ : WU - 1];                                                           \
+        }                                                                                                   \
+    }
+#define QGX_PW_STORE(V)                                                                                     \
+    {                                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < WPT; ++u) {                                                   \
+            const int it_ = u * NTHR + threadIdx.x;                                                          \
+            if (it_ < WU) *reinterpret_cast<f32x4 *>(wA + it_ * 16) = V[u];                                 \
+        }                                                                                                   \
+    }
+
+    // ---- prologue: epilogue parameters, layer B's weights (resident), first input chunk and weight slice
+    for (int i = threadIdx.x; i < 96; i += NTHR) {
+        epA[i] = i < 32 ? a.biasA[i] : (i < 64 ? a.scaleA[i - 32] : a.shiftA[i - 64]);
+        epB[i] = i < 32 ? a.biasB[i] : (i < 64 ? a.scaleB[i - 32] : a.shiftB[i - 64]);
+    }
+    {
+        f32x4 pv[PPT], wv[WPT], wtmp[(WB_BYTES / 16 + NTHR - 1) / NTHR];
+        QGX_PP_LOAD(0, 0, pv)
+        QGX_PW_LOAD(0, wv)
+        QGX_BULK_LOAD(wtmp, a.wB, WB_BYTES / 16, NTHR)
+        QGX_PP_STORE(pv)
+        QGX_PW_STORE(wv)
+        QGX_BULK_STORE(wtmp, wB, WB_BYTES / 16, NTHR)
+    }
+    __syncthreads();
+    QGX_STAMP()
+
+    // per-lane base addresses (tap offsets are compile-time): phase A tile slot mt -> pixel of the RA x NN
+    // block, phase B -> pixel of the R x NN block; both patches put pixel (r, x) at row r, column x
+    int abase[MTA], bbase[MTB];
+    bool avalid[MTA];
+#pragma unroll
+    for (int mt = 0; mt < MTA; ++mt) {
+        const int tile = wave + NW * mt;
+        avalid[mt] = tile < NTA;                         // wave-uniform
+        const int p = (avalid[mt] ? tile : 0) * 32 + li;
+        const int r = p / NN, x = p - r * NN;
+        abase[mt] = (r * PW + x) * ASTR + h * 32;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTB; ++mt) {
+        const int p = (wave + NW * mt) * 32 + li;
+        const int r = p / NN, x = p - r * NN;
+        bbase[mt] = (r * PW + x) * MSTR + h * 32;
+    }
+    const int wofs = (h * 32 + li) * 16;
+
+    for (int ti = 0; ti < n_my; ++ti) {
+        const bool have_next_tile = ti + 1 < n_my;
+        // ================= phase A =================
+        f32x16 accA[MTA];
+#pragma unroll
+        for (int mt = 0; mt < MTA; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[mt][r] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCA; ++ch) {
+            f32x4 pv[PPT], wv[WPT];
+            if (ch + 1 < NCA) QGX_PP_LOAD(ti, ch + 1, pv)
+            QGX_PW_LOAD(ch + 1 < NCA ? ch + 1 : 0, wv)
+            h8 Pn[MTA][2], Wn[2];
+#define QGX_PA_FRAGS(TAP)                                                                                   \
+            {                                                                                               \
+                const int ky_ = (TAP) / 3, kx_ = (TAP) - 3 * ky_;                                           \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+                    Wn[j] = *reinterpret_cast<const h8 *>(wA + wofs + (TAP) * 2048 + j * 1024);             \
+                _Pragma("unroll") for (int mt = 0; mt < MTA; ++mt)                                          \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                        Pn[mt][j] = *reinterpret_cast<const h8 *>(reg0 + abase[mt] + (ky_ * PW + kx_) * ASTR + j * 16); \
+            }
+            QGX_STAMP()
+            QGX_PA_FRAGS(0)
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                h8 Pc[MTA][2], Wc[2];
+#pragma unroll
+                for (int mt = 0; mt < MTA; ++mt) { Pc[mt][0] = Pn[mt][0]; Pc[mt][1] = Pn[mt][1]; }
+                Wc[0] = Wn[0]; Wc[1] = Wn[1];
+                if (tap + 1 < T) QGX_PA_FRAGS(tap + 1)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MTA; ++mt) {
+                    if (!avalid[mt]) continue;           // wave-uniform: waves 4..7 skip their third slot
+                    accA[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[1], Pc[mt][0], accA[mt], 0, 0, 0);
+                    accA[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[0], Pc[mt][1], accA[mt], 0, 0, 0);
+                    accA[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[0], Pc[mt][0], accA[mt], 0, 0, 0);
+                }
+            }
+#undef QGX_PA_FRAGS
+            QGX_STAMP()
+            __syncthreads();                             // every wave is done with this input chunk and slice
+            QGX_STAMP()
+            QGX_PW_STORE(wv)
+            if (ch + 1 < NCA) {
+                QGX_PP_STORE(pv)
+            } else {
+                // ---- layer A epilogue into the intermediate patch (region shared with the input chunk)
+#pragma unroll
+                for (int mt = 0; mt < MTA; ++mt) {
+                    if (!avalid[mt]) continue;
+                    const int p = (wave + NW * mt) * 32 + li;
+                    const int r = p / NN, x = p - r * NN;
+                    char *dst = reg0 + (r * PW + x + 1) * MSTR;
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c0 = 8 * q + 4 * h;
+                        const f32x4 bi = *reinterpret_cast<const f32x4 *>(epA + c0);
+                        const f32x4 sc = *reinterpret_cast<const f32x4 *>(epA + 32 + c0);
+                        const f32x4 sh = *reinterpret_cast<const f32x4 *>(epA + 64 + c0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[4 * q + e] = (fmaxf(accA[mt][4 * q + e] * a.unscaleA + bi[e], 0.f) * sc[e] + sh[e]) * a.ascale;
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        float hi[8], lo[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const _Float16 xh = (_Float16)v[8 * m + e];
+                            hi[e] = (float)xh;
+                            lo[e] = v[8 * m + e] - hi[e];
+                        }
+                        const int g = 2 * m + h;
+                        unsigned a0 = pack_h2(hi[0], hi[1]), a1 = pack_h2(hi[2], hi[3]);
+                        unsigned b0 = pack_h2(hi[4], hi[5]), b1 = pack_h2(hi[6], hi[7]);
+                        auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                        auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                        const u32x4 oh = {s0[0], s1[0], s0[1], s1[1]};
+                        a0 = pack_h2(lo[0], lo[1]); a1 = pack_h2(lo[2], lo[3]);
+                        b0 = pack_h2(lo[4], lo[5]); b1 = pack_h2(lo[6], lo[7]);
+                        s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                        s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                        const u32x4 ol = {s0[0], s1[0], s0[1], s1[1]};
+                        *reinterpret_cast<u32x4 *>(dst + g * 32) = oh;
+                        *reinterpret_cast<u32x4 *>(dst + g * 32 + 16) = ol;
+                        if (x == 0) {                    // wrapped x-halo: column N+1 repeats column 1 ...
+                            *reinterpret_cast<u32x4 *>(dst + NN * MSTR + g * 32) = oh;
+                            *reinterpret_cast<u32x4 *>(dst + NN * MSTR + g * 32 + 16) = ol;
+                        }
+                        if (x == NN - 1) {               // ... and column 0 repeats column N
+                            *reinterpret_cast<u32x4 *>(dst - NN * MSTR + g * 32) = oh;
+                            *reinterpret_cast<u32x4 *>(dst - NN * MSTR + g * 32 + 16) = ol;
+                        }
+                    }
+                }
+            }
+            QGX_STAMP()
+            __syncthreads();
+        }
+
+        // ================= phase B =================
+        f32x16 accB[MTB];
+#pragma unroll
+        for (int mt = 0; mt < MTB; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[mt][r] = 0.f;
+        f32x4 pv[PPT];
+        QGX_PP_LOAD(have_next_tile ? ti + 1 : ti, 0, pv)
+        {
+            h8 Pn[MTB][2], Wn[2];
+#define QGX_PB_FRAGS(S)                                                                                     \
+            {                                                                                               \
+                const int tap_ = (S) >> 1, t_ = (S) & 1, ky_ = tap_ / 3, kx_ = tap_ - 3 * ky_;              \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+                    Wn[j] = *reinterpret_cast<const h8 *>(wB + wofs + t_ * WSLICE + tap_ * 2048 + j * 1024); \
+                _Pragma("unroll") for (int mt = 0; mt < MTB; ++mt)                                          \
+                    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+                        Pn[mt][j] = *reinterpret_cast<const h8 *>(reg0 + bbase[mt] + (ky_ * PW + kx_) * MSTR + t_ * 64 + j * 16); \
+            }
+            QGX_STAMP()
+            QGX_PB_FRAGS(0)
+#pragma unroll
+            for (int s = 0; s < 2 * T; ++s) {
+                h8 Pc[MTB][2], Wc[2];
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) { Pc[mt][0] = Pn[mt][0]; Pc[mt][1] = Pn[mt][1]; }
+                Wc[0] = Wn[0]; Wc[1] = Wn[1];
+                if (s + 1 < 2 * T) QGX_PB_FRAGS(s + 1)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) {
+                    accB[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[1], Pc[mt][0], accB[mt], 0, 0, 0);
+                    accB[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[0], Pc[mt][1], accB[mt], 0, 0, 0);
+                    accB[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[0], Pc[mt][0], accB[mt], 0, 0, 0);
+                }
+            }
+#undef QGX_PB_FRAGS
+        }
+        QGX_STAMP()
+        __syncthreads();                                 // every wave is done with the intermediate patch
+        QGX_STAMP()
+        if (have_next_tile) QGX_PP_STORE(pv)
+        QGX_STAMP()
+        __syncthreads();
+        // ---- layer B epilogue (after the prefetch was retired: its stores drain under the next tile)
+        {
+            const int tile_g = blockIdx.x + ti * gridDim.x;
+            const int b = tile_g / tiles_per_img;
+            const int y0 = (tile_g - b * tiles_per_img) * R;
+#pragma unroll
+            for (int mt = 0; mt < MTB; ++mt) {
+                const int p = (wave + NW * mt) * 32 + li;
+                if constexpr (LAST) {
+                    // bare conv: channel c <= 1 is register c of the lanes with h = 0
+                    if (h == 0) {
+                        float *o = reinterpret_cast<float *>(a.out) + (size_t)b * a.n_out * N * N + (size_t)y0 * N + p;
+                        o[0] = accB[mt][0] * a.unscaleB + epB[0];
+                        if (a.n_out > 1) o[(size_t)N * N] = accB[mt][1] * a.unscaleB + epB[1];
+                    }
+                } else {
+                    constexpr int OPIXB = 32 * 4;
+                    char *pix = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N + p) * OPIXB;
+                    store_tile_t<2, BOUTF32>(accB[mt], 0, h, pix, epB, epB + 32, epB + 64, a.unscaleB, BOUTF32 ? 1.f : a.ascale);
+                }
+            }
+        }
+        QGX_STAMP()
+    }
+#undef QGX_PP_LOAD
+#undef QGX_PP_STORE
+#undef QGX_PW_LOAD
+#undef QGX_PW_STORE
+}
