@@ -177,14 +177,17 @@ def main():
         achieved = flop_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
         # HBM traffic of that kernel cannot be measured from inside this process: it comes from
         # the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-                pt = json.load(f)
-            if pt['config'] == {'nx': N, 'members_per_gpu': B, 'kind': args.kind}:
-                traffic = pt['traffic_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            pass
+        def pmc_traffic(name):
+            try:
+                with open(os.path.join(ROOT, 'profiles', name)) as f:
+                    pt = json.load(f)
+                if pt['config'] == {'nx': N, 'members_per_gpu': B, 'kind': args.kind}:
+                    return pt['traffic_bytes_per_launch']
+            except (OSError, KeyError, ValueError):
+                pass
+            return None
+        traffic = pmc_traffic('pmc_traffic.json')
+        traffic_h = pmc_traffic('pmc_traffic_f16x3.json')
         gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
         # peak for ALGORITHMIC flops: f16x3 executes three f16 MFMAs per algorithmic multiply-add
         mfma_per_mac = {'f32': 1, 'f16x3': 3, 'f16': 1}[args.precision]
@@ -194,7 +197,7 @@ def main():
                           'product, f32 accumulate (error vs a float64 ground truth <= the exact-f32 path, '
                           'tests/test_gpu_precision.py)',
                  'f16': 'f64 spectral core + f16-operand generator (f32 accumulate, TF32-class)'}[args.precision]
-        kname = 'k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh<128,64,5x5>'
+        kname = 'k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh2<128,64,5x5>'
         out = {
             'metric': 'ensemble-timesteps/sec, 64^2 2-layer eddy + GAN param',
             'value': value, 'unit': 'ensemble-timesteps/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -209,7 +212,8 @@ def main():
                        'parallelism': f'ensemble-sharded x{world}, no data-path collective'},
             'roofline': {'bound': 'mfma', 'kernel': f'{kname} (generator layer 2)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic if args.precision == 'f32' else None,
+                         'frac': achieved / peak,
+                         'traffic': traffic if args.precision == 'f32' else (traffic_h if args.precision == 'f16x3' else None),
                          'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_s * 1e3,
                          'launches_timed': l2_n,
                          'executed_mfma_tflops': achieved * mfma_per_mac,

@@ -713,6 +713,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_half_min_tiles = 40;
     int opt_fuse = 2;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
     int opt_pair = 1;              // 3x3 k_convh2: fetch both 64-byte halves of a pixel's 128-byte line together
     int opt_h2 = 3;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
@@ -1089,10 +1090,25 @@ static int rows_half(int N) {
     if ((size_t)(R + 4) * N * 80 + 2 * 5 * 4 * 64 * 16 > 160 * 1024 - 256) return 0;
     return R;
 }
+// rows per tile of k_convh2 (4 waves x MT M-tiles of 32 pixels), 0 when the grid size has no specialisation
+static int rows_h2(int N) {
+    switch (N) {
+        case 32: return 8;
+        case 48: return 8;
+        case 64: return 4;
+        case 96: return 4;
+        case 128: return 2;
+        default: return 0;
+    }
+}
+// the 16-bit path wins from about 40 tiles on (measured crossover: B = 3 at 64x64, 2 at 96x96, 1 at
+// 128x128; "half_min_tiles"); smaller ensembles use the exact-f32 split-K kernels
 static bool half_path_ok(const qgx_generator *g, int B, int N) {
-    const int R = g->opt_half_nw == 4 ? choose_rows(N) : rows_half(N);
-    if (R <= 0 || N % R || N > 128 || choose_rows(N) <= 0) return false;
-    return B * (N / R) >= (g->opt_half_nw == 4 ? 256 : 128);
+    if (N > 128 || choose_rows(N) <= 0) return false;
+    int R = (g->opt_h2 == 3 && g->opt_precision == 3) ? rows_h2(N) : 0;
+    if (R == 0) R = g->opt_half_nw == 4 ? choose_rows(N) : rows_half(N);
+    if (R <= 0 || N % R) return false;
+    return B * (N / R) >= g->opt_half_min_tiles;
 }
 
 template <int CIN, int COUT, int KS, int NS, bool OUTF32>
@@ -1537,6 +1553,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "h2")) g->opt_h2 = value & 3;
     else if (!strcmp(name, "pair")) g->opt_pair = value ? 1 : 0;
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
+    else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
     else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= 0 && value <= 12, "ascale_log2 must be in 0..12"); g->opt_ascale = ldexpf(1.f, value); }

@@ -255,11 +255,19 @@ def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd
             assert _rel(qh[b], m.qh) < 2e-6, (s, b)
 
 
-def test_on_device_noise_run_is_reproducible_and_member_streams_differ():
+@pytest.mark.parametrize('mode', ['f32', 'f16x3'])
+def test_on_device_noise_run_is_reproducible_and_member_streams_differ(mode):
+    """Bit-for-bit: run-to-run, and a shard of an ensemble against the whole ensemble.  Results are
+    independent of the ensemble size as long as both sides run the same generator arithmetic (the
+    automatic choice switches kernels with the number of resident members), so it is pinned here."""
     import pyqg_generative_amd._lib as L
     N, B = 64, 4
     q0 = _eddy_like_q(np.random.RandomState(1), 1, N).repeat(B, axis=0)
     gen = _gpu_generator('gan')
+    if mode == 'f32':
+        gen.set_option('precision', 0)
+    else:
+        gen.set_option('half_min_tiles', 1)
     outs = []
     for trial in range(2):
         e = _engine(N, B, dt=14400.)
