@@ -43,6 +43,7 @@ extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
 #include "conv_half.hpp"
 #include "conv_pair.hpp"
+#include "conv_h16.hpp"
 
 // OUTH = 0: f32 NHWC output.  OUTH = 1 / 2 (first layer only): the MFMA roles are swapped (lane = pixel)
 // and the epilogue writes the packed f16 / f16 hi-lo activation layout of conv_half.hpp.
@@ -689,6 +690,7 @@ struct LayerHost {
     float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
     void *wh[2] = {nullptr, nullptr};        // conv_half.hpp layouts: [0] f16 (NS = 1), [1] f16 hi/lo (NS = 2)
     float wh_unscale[2] = {1.f, 1.f};        // 2^-s of the power-of-two weight pre-scale
+    void *wh16 = nullptr;                    // k_convh3 (16x16x32 MFMA): [chunk32][tap][part][octet][cout][8] f16
     void *whf = nullptr;                     // first layer, f16x3: [step][part][h][128][8] f16
     float whf_unscale = 1.f;
 };
@@ -713,6 +715,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
     int opt_half_min_tiles = 40;
     int opt_fuse = 2;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
     int opt_pair = 1;              // 3x3 k_convh2: fetch both 64-byte halves of a pixel's 128-byte line together
@@ -798,6 +801,29 @@ static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
     return QGX_OK;
 }
 
+// k_convh3 layout: 32-channel chunks, [chunk][tap][part][octet][cout][8]; same power-of-two pre-scale as wh[1]
+static int pack_half16(LayerHost &L, int li, const qgx_cnn_weights *w) {
+    const int cin = L.cin, cout = L.cout, T = L.ks * L.ks, nch = cin / 32;
+    const float *W = w->conv_w[li];
+    const float sc = 1.0f / L.wh_unscale[1];
+    std::vector<_Float16> pw((size_t)nch * T * 2 * 4 * cout * 8, (_Float16)0.f);
+    for (int ch = 0; ch < nch; ++ch)
+        for (int t = 0; t < T; ++t)
+            for (int part = 0; part < 2; ++part)
+                for (int o = 0; o < 4; ++o)
+                    for (int co = 0; co < cout; ++co)
+                        for (int e8 = 0; e8 < 8; ++e8) {
+                            const int c = ch * 32 + o * 8 + e8;
+                            const float x = W[((size_t)co * cin + c) * T + t] * sc;
+                            const _Float16 xh = (_Float16)x;
+                            pw[(((((size_t)ch * T + t) * 2 + part) * 4 + o) * cout + co) * 8 + e8] =
+                                part == 0 ? xh : (_Float16)(x - (float)xh);
+                        }
+    QGX_HIP(hipMalloc(&L.wh16, pw.size() * sizeof(_Float16)));
+    QGX_HIP(hipMemcpy(L.wh16, pw.data(), pw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    return QGX_OK;
+}
+
 // first layer, f16x3 (k_convh_first): [step][part][h][cout][8], element j of lane half h in step s is
 // (tap, channel) = (TPS s + TPF h + j / n_in, j % n_in); tap slots >= 25 hold zeros
 static int pack_half_first(LayerHost &L, const qgx_cnn_weights *w) {
@@ -856,6 +882,7 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
         }
         if (li < 7) {
             if ((rc = pack_half(L, li, w, 1)) || (rc = pack_half(L, li, w, 2))) return rc;
+            if (li == 1 && (rc = pack_half16(L, li, w))) return rc;
         } else if ((rc = pack_half(L, li, w, 2))) return rc;      // fused (layer 7, layer 8) pair
     }
     if (li == 7) {      // [tap][c][2] for the VALU last-layer kernel
@@ -1256,6 +1283,32 @@ static int conv3x3_half(qgx_generator *g, int layer, const LayerHost &L, const v
     return launch_convh<CIN, COUT, 3, NS, OUTF32>(g, layer, L, in, out, B, N, st);
 }
 
+// the 128 -> 64, 5x5 layer on 16x16x32 MFMAs (k_convh3); grids whose rows tile 256 pixels
+static int launch_convh3(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                         hipStream_t st, bool &done) {
+    done = false;
+    if (N != 64 || !L.wh16) return QGX_OK;
+    constexpr int NN = 64, R = 256 / NN, PR = R + 4, PW = NN + 4;
+    constexpr size_t lds = (size_t)4 * PR * PW * 48 + (size_t)5 * 2 * 4 * 64 * 16 + 3 * 64 * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS");
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    ConvHArgs a = {};
+    a.in = in; a.out = out; a.w = L.wh16; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
+    a.N = N; a.R = R;
+    const int total_tiles = B * (N / R);
+    int grid = 256;
+    if (grid > total_tiles) grid = total_tiles;
+    auto kern = k_convh3<NN>;
+    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    done = true;
+    return QGX_OK;
+}
+
 // two fused 3x3 layers (k_convh_pair); 64 x 64 grids
 template <int CINA, bool LAST, bool BOUTF32>
 static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, const LayerHost &LB, const void *in,
@@ -1337,7 +1390,8 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         if (rc) return rc;
         bool done1 = false;
-        if (NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
+        if (NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, net.L[1], A, Bb, Bc, N, st))) return rc;
         if (NS == 2 && g->opt_fuse && N == 64 && net.n_out <= 2) {
             // 3x3 layers fused pairwise (the intermediate activation stays in LDS); "fuse" bits: 1 = layers
@@ -1498,6 +1552,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             for (float *p : ptrs) if (p) (void)hipFree(p);
             for (void *p : L.wh) if (p) (void)hipFree(p);
             if (L.whf) (void)hipFree(L.whf);
+            if (L.wh16) (void)hipFree(L.wh16);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
     for (float *p : bufs) if (p) (void)hipFree(p);
@@ -1553,6 +1608,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "h2")) g->opt_h2 = value & 3;
     else if (!strcmp(name, "pair")) g->opt_pair = value ? 1 : 0;
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
+    else if (!strcmp(name, "h3")) g->opt_h3 = value ? 1 : 0;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
