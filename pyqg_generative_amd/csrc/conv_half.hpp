@@ -395,6 +395,9 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
     const int li = lane & 31, h = lane >> 5;
     const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     if (n_my == 0) return;
+    int stamp_i = 0;
+    (void)stamp_i;
+    QGX_STAMP()
 
 #define QGX_H2P_LOAD(TI, CH, V)                                                                             \
     {                                                                                                       \
@@ -412,6 +415,27 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
             V[u] = *reinterpret_cast<const f32x4 *>(                                                        \
                 inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 64 + un_ * 16);                    \
         }                                                                                                   \
+    }
+#define QGX_H2P_LOAD1(TI, CH, V, U)                                                                         \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        int it_ = (U) * NTHR + threadIdx.x;                                                                  \
+        it_ = it_ < PU ? it_ : PU - 1;                                                                      \
+        const int un_ = it_ & 3, pl_ = it_ >> 2;                                                            \
+        const int pr_ = pl_ / PW, xx_ = pl_ - pr_ * PW;                                                     \
+        int gy_ = y0_ - P + pr_, gx_ = xx_ - P;                                                             \
+        gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                               \
+        gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                               \
+        V[U] = *reinterpret_cast<const f32x4 *>(                                                            \
+            inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 64 + un_ * 16);                        \
+    }
+#define QGX_H2W_LOAD1(CH, SL, V, U)                                                                         \
+    {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(wb + ((size_t)(CH) * NSL + (SL)) * WSB);        \
+        const int it_ = (U) * NTHR + threadIdx.x;                                                            \
+        V[U] = src_[it_ < WU ? it_ : WU - 1];                                                               \
     }
 #define QGX_H2P_STORE(V)                                                                                    \
     {                                                                                                       \
@@ -486,23 +510,22 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
             const int nti = ch + 1 < NCH ? ti : ti + 1;
             const bool have_next_chunk = nti < n_my;
             f32x4 pv[PAIR ? 1 : PPT];
-            if constexpr (PAIR) {
-                if (ch & 1) {                           // the next pair (nch is even), possibly of the next tile
-                    QGX_H2P_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch - 1, pvA)
-                    QGX_H2P_LOAD(have_next_chunk ? nti : ti, (have_next_chunk ? nch : ch - 1) + 1, pvB)
-                }
-            } else {
-                QGX_H2P_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch, pv)
-            }
+            // the global prefetch loads of a stage (next weight slice; at the first slice of a chunk the next
+            // chunk's patch — PAIR: at odd chunks the next pair, nch is even then) are NOT issued as a burst
+            // in front of the K loop: the CU's vector-memory path takes 64 B per clock, so a burst of 14-19
+            // 1-KB wave loads from every wave kept the in-order waves away from their MFMAs for 1-3 k cycles
+            // per stage (stamped timeline); they are spread over the taps instead, weights first
+            const int p_ti = have_next_chunk ? nti : ti;
+            const int p_ch = PAIR ? (have_next_chunk ? nch : ch - 1) : (have_next_chunk ? nch : ch);
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) {
                 f32x4 wv[WPT];
                 const bool last_stage = !have_next_chunk && sl == NSL - 1;
-                {
-                    const int wch = sl + 1 < NSL ? ch : (have_next_chunk ? nch : ch);
-                    const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
-                    QGX_H2W_LOAD(wch, wsl, wv)
-                }
+                const int wch = sl + 1 < NSL ? ch : (have_next_chunk ? nch : ch);
+                const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
+                const int n_pl = PAIR ? ((ch & 1) ? 2 * PPT : 0) : (sl == 0 ? PPT : 0);   // patch loads of this stage
+                const int n_ld = WPT + n_pl;
+                constexpr int TSPREAD = TPS > 2 ? TPS - 1 : TPS;                       // the last tap carries none
                 const char *wl = wlds0 + (WDB ? cur_w * WSB : 0) + wofs;
                 h8 Pn[MT][2], Wn[NT][2];
 #define QGX_H2_FRAGS(TL)                                                                                    \
@@ -515,6 +538,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                       \
                             Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + pbase[mt] + (ky_ * PW + kx_) * PSTR + j * 16); \
                 }
+                QGX_STAMP()
                 QGX_H2_FRAGS(0)
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
@@ -537,6 +561,19 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                             for (int j = 0; j < 2; ++j)
                                 Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + pbase[mt] + (ky_ * PW + kx_) * PSTR + j * 16);
                     }
+#pragma unroll
+                    for (int i = 0; i < WPT + 2 * PPT; ++i) {
+                        if (i < n_ld && (i * TSPREAD) / n_ld == tl) {
+                            if (i < WPT) {
+                                QGX_H2W_LOAD1(wch, wsl, wv, i)
+                            } else if constexpr (PAIR) {
+                                if (i - WPT < PPT) { QGX_H2P_LOAD1(p_ti, p_ch, pvA, i - WPT) }
+                                else { QGX_H2P_LOAD1(p_ti, p_ch + 1, pvB, i - WPT - PPT) }
+                            } else {
+                                if (i - WPT < PPT) QGX_H2P_LOAD1(p_ti, p_ch, pv, i - WPT)
+                            }
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
@@ -548,10 +585,12 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                         }
                 }
 #undef QGX_H2_FRAGS
+                QGX_STAMP()
                 // ---- retire the prefetches
                 if constexpr (WDB) {
                     if (sl == NSL - 1) {
                         __syncthreads();
+                        QGX_STAMP()
                         if constexpr (PAIR) {
                             if (ch & 1) { if (have_next_chunk) QGX_H2P_STORE(pvA) } else QGX_H2P_STORE(pvB)
                         } else {
@@ -559,7 +598,9 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                         }
                     }
                     if (!last_stage) QGX_H2W_STORE(wlds0 + (cur_w ^ 1) * WSB, wv)
+                    QGX_STAMP()
                     __syncthreads();
+                    QGX_STAMP()
                     cur_w ^= 1;
                 } else {
                     __syncthreads();                     // every wave is done with this slice (and chunk)
@@ -584,6 +625,8 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
         }
     }
 #undef QGX_H2P_LOAD
+#undef QGX_H2P_LOAD1
+#undef QGX_H2W_LOAD1
 #undef QGX_H2P_STORE
 #undef QGX_H2W_LOAD
 #undef QGX_H2W_STORE
