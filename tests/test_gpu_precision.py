@@ -89,3 +89,44 @@ def test_split_f16_golden_vectors(kind):
         err = (np.abs(S - S_ref) / np.abs(S_ref).max(axis=(1, 2), keepdims=True)).max()
         print(f'\n{kind} N={N}: f16x3 vs golden {err:.2e}')
         assert err < 2e-5
+
+
+VARIANTS = [
+    dict(h2=0, half_nw=8, res=0, fuse=0),        # generic run-time-N kernel k_convh, 8 waves
+    dict(h2=0, half_nw=4, res=0, fuse=0),        # ... 4 waves, swizzled 64-byte patch pixels
+    dict(h2=0, half_nw=8, res=1, fuse=0),        # resident-weight 3x3 kernel k_convh_res
+    dict(h2=3, pair=0, fuse=0),                  # k_convh2 without the line-pair fetch
+    dict(h2=3, fuse=7),                          # every 3x3 pair fused (k_convh_pair)
+    dict(h2=3, fuse=1),
+    dict(h3=1),                                  # 5x5 layer on 16x16x32 MFMAs (k_convh3)
+    dict(first_h=0),                             # exact-f32 first layer writing the 16-bit layout
+    dict(member_chunk=16),                       # member sub-batches
+]
+
+
+@pytest.mark.parametrize('N,B', [(64, 16), (96, 8), (48, 16)])
+def test_optional_kernel_variants_agree(N, B):
+    """every selectable f16x3 kernel variant against the exact-f32 path: float32 tolerance (2e-5 of the
+    maximum); options that do not apply to a grid size fall back to the default kernels"""
+    gen = _gpu_generator('gan')
+    rs = np.random.RandomState(7 * N + B)
+    x = torch.as_tensor(rs.randn(B, 4, N, N).astype('float32'), device='cuda')
+    gen.set_option('precision', 0)
+    ref = gen.cnn_forward(x).cpu().numpy()
+    gen.set_option('precision', 3)
+    gen.set_option('half_min_tiles', 1)
+    defaults = dict(h2=3, half_nw=8, res=1, fuse=2, pair=1, h3=0, first_h=1, member_chunk=0)
+    for v in VARIANTS:
+        for k, d in defaults.items():
+            gen.set_option(k, v.get(k, d))
+        y = gen.cnn_forward(x).cpu().numpy()
+        err = _maxrel(y, ref)
+        assert err < 2e-5, (v, err)
+    # plain f16 operands through the generic kernels (both wave counts): TF32-class tolerance
+    gen.set_option('precision', 1)
+    for nw in (8, 4):
+        for k, d in defaults.items():
+            gen.set_option(k, d)
+        gen.set_option('half_nw', nw)
+        err = _maxrel(gen.cnn_forward(x).cpu().numpy(), ref)
+        assert err < 1e-2, (nw, err)
