@@ -976,10 +976,9 @@ static bool small_ensemble(int B, int N) {
     return R > 0 && B * (N / R) <= 192 && rows_small(N) > 0 && rows_small(N) < R;   // crossover ~ B=13 at 64x64
 }
 
-template <int CIN, int COUT, int KS>
+template <int CIN, int COUT, int KS, int CC = 32>
 static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                              int N, hipStream_t st) {
-    constexpr int CC = 32;
     const int R = rows_small(N);                   // <= 4 M-tiles of 32 pixels
     const int nsplit = CIN >= 64 ? CIN / CC : 1;
     hipEvent_t prof_stop;
@@ -992,7 +991,7 @@ static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, co
         g->part_elems = npix * COUT * nsplit;
     }
     ConvArgs a = {};
-    a.in = in; a.out = nsplit > 1 ? g->part : out; a.w = L.w32; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.in = in; a.out = nsplit > 1 ? g->part : out; a.w = CC == 32 ? L.w32 : L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = COUT; a.npix_total = npix;
     const size_t lds = (size_t)(R + KS - 1) * N * (CC + 4) * sizeof(float);
     dim3 grid(B * (N / R), nsplit), block(256);
@@ -1068,7 +1067,12 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
 template <int CIN, int COUT, int KS>
 static int conv_hidden(qgx_generator *g, int layer, const LayerHost &L, const float *in, float *out, int B,
                        int N, hipStream_t st) {
-    if (g->opt_small && small_ensemble(B, N)) return launch_conv_small<CIN, COUT, KS>(g, layer, L, in, out, B, N, st);
+    if (g->opt_small && small_ensemble(B, N)) {
+        // wide layers: split K per 16-channel chunk (8 / 4 partial sums) so that a single member still spreads
+        // over >= 128 workgroups; the same split for every small ensemble, so that results do not depend
+        // on the member count within this kernel family
+        return launch_conv_small<CIN, COUT, KS, CIN >= 64 ? 16 : 32>(g, layer, L, in, out, B, N, st);
+    }
     bool done = false;
     int rc = QGX_OK;
     const int v3 = g->opt_v3;
