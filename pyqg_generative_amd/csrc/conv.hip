@@ -715,6 +715,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
     int opt_half_min_tiles = 40;
     int opt_fuse = 2;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
@@ -1095,6 +1096,9 @@ static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *i
                             int n_out, hipStream_t st) {
     int R = choose_rows(N);
     if (g->opt_small && R > 0 && B * (N / R) <= 192) R = 1;      // small ensembles: one row per workgroup
+    else if (R > 2 && N % 2 == 0) R = 2;                         // 37-55 KB of LDS: 2-4 workgroups per CU hide the
+                                                                 // load -> barrier -> compute -> store chain (-10..-20 %)
+    if (g->opt_last_rows > 0 && N % g->opt_last_rows == 0) R = g->opt_last_rows;
     QGX_REQUIRE(R > 0 && N % R == 0, "generator: unsupported grid size N=%d", N);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, 7, st, prof_stop); if (prc) return prc; }
@@ -1614,6 +1618,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "pair")) g->opt_pair = value ? 1 : 0;
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
     else if (!strcmp(name, "h3")) g->opt_h3 = value ? 1 : 0;
+    else if (!strcmp(name, "last_rows")) g->opt_last_rows = value;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
