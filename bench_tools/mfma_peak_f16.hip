@@ -63,6 +63,7 @@ __global__ __launch_bounds__(NWV * 64) void k4(float *out, int iters, unsigned l
     out[blockIdx.x * NWV * 64 + threadIdx.x] = s;
 }
 
+__device__ int g_zero_pct = 0;   // percentage of exact zeros in the pixel-operand table (post-ReLU activations)
 template <int mode>
 __global__ __launch_bounds__(512) void k(float *out, int iters, unsigned long long *clk) {
     __shared__ h8 lds[4096];
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, unsigned long lo
         for (int e = 0; e < 8; ++e) {
             unsigned x = ((i * 8 + e) * 2654435761u) ^ 0x9E3779B9u;
             v[e] = (_Float16)(((x >> 8) & 4095) * (1.f / 4096.f) - 0.5f);
+            if (i < 2048 && (int)((x >> 20) % 100) < g_zero_pct) v[e] = (_Float16)0.f;
         }
         lds[i] = v;
     }
@@ -131,7 +133,10 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, unsigned long lo
 int main() {
     float *d; hipMalloc(&d, 1024 * 512 * 4);
     unsigned long long *clk; hipMalloc(&clk, 16);
-    for (int mode = 0; mode < 6; ++mode) {
+    for (int zp = 0; zp <= 75; zp += 25)
+    for (int mode = (zp ? 1 : 0); mode < (zp ? 2 : 6); ++mode) {
+        hipMemcpyToSymbol(HIP_SYMBOL(g_zero_pct), &zp, sizeof(int));
+        if (zp) printf("pixel operand with %d %% zeros: ", zp);
         const int grid = 256, iters = 20000;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         float best = 1e9; unsigned long long h[2] = {0, 0};
