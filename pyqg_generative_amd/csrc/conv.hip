@@ -715,9 +715,10 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_part_max_tiles = 112;  // f16x3: split K on the wide layers below this many tiles (crossover: 7 members at 64x64)
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
-    int opt_half_min_tiles = 40;
+    int opt_half_min_tiles = 1;
     int opt_fuse = 2;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
     int opt_pair = 1;              // 3x3 k_convh2: fetch both 64-byte halves of a pixel's 128-byte line together
     int opt_h2 = 3;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
@@ -1136,8 +1137,9 @@ static int rows_h2(int N) {
         default: return 0;
     }
 }
-// the 16-bit path wins from about 40 tiles on (measured crossover: B = 3 at 64x64, 2 at 96x96, 1 at
-// 128x128; "half_min_tiles"); smaller ensembles use the exact-f32 split-K kernels
+// with the split-K variant for single members the 16-bit path wins at every ensemble size on the grids
+// k_convh2 is specialised for, so it is always taken there ("half_min_tiles" = 1; raise it to send small
+// ensembles to the exact-f32 split-K kernels)
 static bool half_path_ok(const qgx_generator *g, int B, int N) {
     if (N > 128 || choose_rows(N) <= 0) return false;
     int R = (g->opt_h2 == 3 && g->opt_precision == 3) ? rows_h2(N) : 0;
@@ -1224,6 +1226,57 @@ static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, cons
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
+}
+
+// single members: split K over the 16-channel chunks (k_convh2<PART> + k_convh_reduce), so that the wide
+// layers spread over >= 64 workgroups
+template <int CIN, int COUT, int KS, bool OUTF32, int NN, int MT>
+static int launch_convh2_part_n(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B,
+                                hipStream_t st) {
+    constexpr int TPS = KS == 5 ? 5 : 9, NCH = CIN / 16;
+    constexpr int R = 4 * MT * 32 / NN, PR = R + KS - 1, PW = NN + 2 * (KS / 2);
+    constexpr bool WDB = KS == 3;
+    constexpr size_t lds = (size_t)PR * PW * 80 + (size_t)(WDB ? 2 : 1) * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
+    constexpr int nsplit = NCH >= 8 ? 8 : NCH;
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    const size_t npix = (size_t)B * NN * NN;
+    if (g->part_elems < npix * COUT * nsplit) {
+        if (g->part) (void)hipFree(g->part);
+        g->part = nullptr; g->part_elems = 0;
+        QGX_HIP(hipMalloc((void **)&g->part, npix * COUT * nsplit * sizeof(float)));
+        g->part_elems = npix * COUT * nsplit;
+    }
+    ConvHArgs a = {};
+    a.in = in; a.out = g->part; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.N = NN; a.R = R; a.npix_total = npix;
+    const int total_tiles = B * (NN / R);
+    constexpr bool TWO = lds * 2 <= 160 * 1024 && MT == 2;
+    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO, false, true>;
+    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(total_tiles, nsplit), dim3(256), lds, st, a, total_tiles);
+    const size_t n = npix * (COUT / 8);
+    hipLaunchKernelGGL((k_convh_reduce<COUT, OUTF32>), dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
+                       (const float *)g->part, nsplit, npix, (const float *)L.bias, (const float *)L.scale, (const float *)L.shift,
+                       a.unscale, a.ascale, out);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
+}
+
+template <int CIN, int COUT, int KS, bool OUTF32>
+static int launch_convh2_part(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                              hipStream_t st, bool &done) {
+    done = true;
+    switch (N) {
+        case 32: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 32, 2>(g, layer, L, in, out, B, st);
+        case 48: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 48, 3>(g, layer, L, in, out, B, st);
+        case 64: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 64, 2>(g, layer, L, in, out, B, st);
+        case 96: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 96, 3>(g, layer, L, in, out, B, st);
+        case 128: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 128, 2>(g, layer, L, in, out, B, st);
+        default: done = false; return QGX_OK;
+    }
 }
 
 template <int CIN, int COUT, int KS, bool OUTF32>
@@ -1398,10 +1451,26 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         } else if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         if (rc) return rc;
+        // single members / tiny ensembles (fewer than "part_max_tiles" tiles): split K on the two wide layers and
+        // do not fuse (7, 8) (8 tiles of 512 pixels would leave 248 CUs idle)
+        const int r2 = rows_h2(N);
+        const bool tiny = NS == 2 && g->opt_h2 == 3 && r2 > 0 && Bc * (N / r2) < g->opt_part_max_tiles;
         bool done1 = false;
-        if (NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
+        if (tiny && (rc = launch_convh2_part<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, net.L[1], A, Bb, Bc, N, st))) return rc;
+        if (tiny) {
+            bool done2 = false;
+            if ((rc = launch_convh2_part<64, 32, 3, false>(g, 2, net.L[2], Bb, A, Bc, N, st, done2))) return rc;
+            if (!done2 && (rc = conv3x3_half<64, 32, NS, false>(g, 2, net.L[2], Bb, A, Bc, N, st))) return rc;
+            if ((rc = conv3x3_half<32, 32, NS, false>(g, 3, net.L[3], A, Bb, Bc, N, st))) return rc;
+            if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], Bb, A, Bc, N, st))) return rc;
+            if ((rc = conv3x3_half<32, 32, NS, false>(g, 5, net.L[5], A, Bb, Bc, N, st))) return rc;
+            if ((rc = conv3x3_half<32, 32, NS, true>(g, 6, net.L[6], Bb, A, Bc, N, st))) return rc;
+            if ((rc = launch_conv_last(g, net.L[7], A, yc, Bc, N, net.n_out, st))) return rc;
+            continue;
+        }
         if (NS == 2 && g->opt_fuse && N == 64 && net.n_out <= 2) {
             // 3x3 layers fused pairwise (the intermediate activation stays in LDS); "fuse" bits: 1 = layers
             // (5, 6), 2 = layers (7, 8), 4 = layers (3, 4) — the 64-channel pair measured slower fused
@@ -1619,6 +1688,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
     else if (!strcmp(name, "h3")) g->opt_h3 = value ? 1 : 0;
     else if (!strcmp(name, "last_rows")) g->opt_last_rows = value;
+    else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }

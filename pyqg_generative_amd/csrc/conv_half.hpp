@@ -41,6 +41,7 @@ struct ConvHArgs {
     float unscale;         // 1 / (weight pre-scale * input activation pre-scale), a power of two
     float ascale;          // pre-scale of the stored output activations, a power of two
     int N, R;
+    size_t npix_total;     // split-K: B*N*N, the stride of one partial-sum plane
     unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only: s_memtime trace, 64 slots per workgroup
 };
 
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles)
 // KS/2 columns on both sides, so a tap is a compile-time byte offset from ONE per-lane base address
 // (ds_read offset immediates, no address arithmetic, no address registers).  The weight slice is single
 // buffered where two buffers would not leave room for two workgroups (the 5x5 layer).
-template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB, bool TWO, bool PAIR = false>
+template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB, bool TWO, bool PAIR = false, bool PART = false>
 __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int total_tiles) {
     constexpr int NW = 4, NTHR = 256;
     constexpr int NT = COUT / 32;
@@ -385,6 +386,11 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
     constexpr int WU = WSB / 16, WPT = (WU + NTHR - 1) / NTHR;
     static_assert(T % TPS == 0 && (NW * MT * 32) % NN == 0 && NN % R == 0, "shape");
     static_assert(!PAIR || (NCH % 2 == 0 && NSL == 1), "line-pair prefetch: even chunk count, one slice per chunk");
+    static_assert(!(PAIR && PART), "split-K runs without the line-pair prefetch");
+    // PART (single members): blockIdx.y owns the chunks [cbeg, cend) of every tile and stores raw f32 partial
+    // sums [split][pixel][cout]; k_convh_reduce adds them in a fixed order and applies the epilogue
+    const int cbeg = PART ? (int)blockIdx.y * (NCH / (int)gridDim.y) : 0;
+    const int cend = PART ? cbeg + NCH / (int)gridDim.y : NCH;
     char *const lds0 = conv_smem;
     char *const wlds0 = lds0 + patch_bytes;
     float *const ep = reinterpret_cast<float *>(wlds0 + (WDB ? 2 : 1) * WSB);
@@ -474,11 +480,11 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
             QGX_H2P_STORE(pvA)
         } else {
             f32x4 pv[PPT];
-            QGX_H2P_LOAD(0, 0, pv)
+            QGX_H2P_LOAD(0, cbeg, pv)
             QGX_H2P_STORE(pv)
         }
         f32x4 wv[WPT];
-        QGX_H2W_LOAD(0, 0, wv)
+        QGX_H2W_LOAD(cbeg, 0, wv)
         QGX_H2W_STORE(wlds0, wv)
     }
     __syncthreads();
@@ -497,8 +503,8 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
     int cur_w = 0;
     for (int ti = 0; ti < n_my; ++ti) {
 #pragma unroll(PAIR ? NCH : 1)
-        for (int ch = 0; ch < NCH; ++ch) {
-            if (ch == 0) {
+        for (int ch = cbeg; ch < cend; ++ch) {
+            if (ch == cbeg) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -506,8 +512,8 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
             }
-            const int nch = ch + 1 < NCH ? ch + 1 : 0;
-            const int nti = ch + 1 < NCH ? ti : ti + 1;
+            const int nch = ch + 1 < cend ? ch + 1 : cbeg;
+            const int nti = ch + 1 < cend ? ti : ti + 1;
             const bool have_next_chunk = nti < n_my;
             f32x4 pv[PAIR ? 1 : PPT];
             // the global prefetch loads of a stage (next weight slice; at the first slice of a chunk the next
@@ -608,17 +614,32 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                     if constexpr (!PAIR) { if (sl == NSL - 1 && have_next_chunk) QGX_H2P_STORE(pv) }
                     __syncthreads();
                 }
-                if (sl == NSL - 1 && ch == NCH - 1) {
+                if (sl == NSL - 1 && ch == cend - 1) {
                     const int tile_g = blockIdx.x + ti * gridDim.x;
                     const int b = tile_g / tiles_per_img;
                     const int y0 = (tile_g - b * tiles_per_img) * R;
-                    char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N) * OPIXB;
+                    if constexpr (PART) {
+                        // raw partial sums, f32 [split][pixel][cout]: register quad q of a lane = 4 consecutive channels
+                        float *pb = reinterpret_cast<float *>(a.out) +
+                                    ((size_t)blockIdx.y * a.npix_total + (size_t)b * N * N + (size_t)y0 * N) * COUT;
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        char *pix = ob + (size_t)((wave + NW * mt) * 32 + li) * OPIXB;
+                        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4) {
+                                    const f32x4 v = {acc[mt][nt][4 * q4], acc[mt][nt][4 * q4 + 1], acc[mt][nt][4 * q4 + 2], acc[mt][nt][4 * q4 + 3]};
+                                    *reinterpret_cast<f32x4 *>(pb + (size_t)((wave + NW * mt) * 32 + li) * COUT + nt * 32 + 8 * q4 + 4 * h) = v;
+                                }
+                    } else {
+                        char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N) * OPIXB;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            char *pix = ob + (size_t)((wave + NW * mt) * 32 + li) * OPIXB;
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                        }
                     }
                 }
             }
@@ -630,6 +651,50 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
 #undef QGX_H2P_STORE
 #undef QGX_H2W_LOAD
 #undef QGX_H2W_STORE
+}
+
+// split-K combine of k_convh2<PART>: out = epilogue(sum_s partial[s]) in a fixed order; one thread per pixel
+// and octet of channels, output in the packed hi/lo layout (or NHWC f32)
+template <int COUT, bool OUTF32>
+__global__ void k_convh_reduce(const float *partial, int nsplit, size_t npix_total, const float *bias, const float *scale,
+                               const float *shift, float unscale, float ascale, void *out) {
+    const size_t n = npix_total * (COUT / 8);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % (COUT / 8));
+        const size_t pix = i / (COUT / 8);
+        const float *p0 = partial + pix * COUT + g * 8;
+        f32x4 v0 = *reinterpret_cast<const f32x4 *>(p0), v1 = *reinterpret_cast<const f32x4 *>(p0 + 4);
+        for (int s2 = 1; s2 < nsplit; ++s2) {
+            v0 += *reinterpret_cast<const f32x4 *>(p0 + (size_t)s2 * npix_total * COUT);
+            v1 += *reinterpret_cast<const f32x4 *>(p0 + (size_t)s2 * npix_total * COUT + 4);
+        }
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = g * 8 + e;
+            const float r = (e < 4 ? v0[e] : v1[e - 4]) * unscale + bias[c];
+            x[e] = fmaxf(r, 0.f) * scale[c] + shift[c];
+        }
+        if constexpr (OUTF32) {
+            float *o = reinterpret_cast<float *>(out) + pix * COUT + g * 8;
+            const f32x4 o0 = {x[0], x[1], x[2], x[3]}, o1 = {x[4], x[5], x[6], x[7]};
+            *reinterpret_cast<f32x4 *>(o) = o0;
+            *reinterpret_cast<f32x4 *>(o + 4) = o1;
+        } else {
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = x[2 * e] * ascale, a1 = x[2 * e + 1] * ascale;
+                const _Float16 h0 = (_Float16)a0, h1 = (_Float16)a1;
+                hw[e] = pack_h2((float)h0, (float)h1);
+                lw[e] = pack_h2(a0 - (float)h0, a1 - (float)h1);
+            }
+            char *o = reinterpret_cast<char *>(out) + pix * (COUT * 4) + g * 32;
+            const u32x4 oh = {hw[0], hw[1], hw[2], hw[3]}, ol = {lw[0], lw[1], lw[2], lw[3]};
+            *reinterpret_cast<u32x4 *>(o) = oh;
+            *reinterpret_cast<u32x4 *>(o + 16) = ol;
+        }
+    }
 }
 
 // ---- first layer (n_in = 4 or 2 planar f32 channels -> 128, 5x5) in the f16x3 arithmetic ---------------

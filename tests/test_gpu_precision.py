@@ -92,6 +92,7 @@ def test_split_f16_golden_vectors(kind):
 
 
 VARIANTS = [
+    dict(part_max_tiles=100000),                 # split-K on the wide layers (single-member path)
     dict(h2=0, half_nw=8, res=0, fuse=0),        # generic run-time-N kernel k_convh, 8 waves
     dict(h2=0, half_nw=4, res=0, fuse=0),        # ... 4 waves, swizzled 64-byte patch pixels
     dict(h2=0, half_nw=8, res=1, fuse=0),        # resident-weight 3x3 kernel k_convh_res
@@ -114,8 +115,8 @@ def test_optional_kernel_variants_agree(N, B):
     gen.set_option('precision', 0)
     ref = gen.cnn_forward(x).cpu().numpy()
     gen.set_option('precision', 3)
-    gen.set_option('half_min_tiles', 1)
-    defaults = dict(h2=3, half_nw=8, res=1, fuse=2, pair=1, h3=0, first_h=1, member_chunk=0)
+    gen.set_option('part_max_tiles', 0)
+    defaults = dict(h2=3, half_nw=8, res=1, fuse=2, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0)
     for v in VARIANTS:
         for k, d in defaults.items():
             gen.set_option(k, v.get(k, d))
