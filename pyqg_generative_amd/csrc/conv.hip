@@ -690,6 +690,10 @@ struct LayerHost {
     float *w = nullptr, *w32 = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;   // w: 16-ch chunks (or planar), w32: 32-ch chunks
     void *wh[2] = {nullptr, nullptr};        // conv_half.hpp layouts: [0] f16 (NS = 1), [1] f16 hi/lo (NS = 2)
     float wh_unscale[2] = {1.f, 1.f};        // 2^-s of the power-of-two weight pre-scale
+    // layer 2 with layer 1's BatchNorm folded in (W' = W alpha[c_in], b' = b + sum W beta'[c_in]; exact under circular
+    // padding): layer 1 then stores ReLU output, half of which is exactly zero -> a sparser MFMA operand
+    void *whF = nullptr; float whF_unscale = 1.f; float *biasF = nullptr;
+    float *ones = nullptr, *zeros = nullptr; // layer 1: identity BatchNorm for the folded variant
     void *wh16 = nullptr;                    // k_convh3 (16x16x32 MFMA): [chunk32][tap][part][octet][cout][8] f16
     void *whf = nullptr;                     // first layer, f16x3: [step][part][h][128][8] f16
     float whf_unscale = 1.f;
@@ -715,6 +719,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
     int opt_part_max_tiles = 112;  // f16x3: split K on the wide layers below this many tiles (crossover: 7 members at 64x64)
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
@@ -771,13 +776,16 @@ static int pack_weights(const LayerHost &L, int li, const qgx_cnn_weights *w, bo
 }
 
 // conv_half.hpp weight layout [chunk][tap][j][h][cout][8] f16, pre-scaled by 2^s with max|w| 2^s in [2^13, 2^14)
-static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
+static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS, const float *cin_scale = nullptr) {
     const int cin = L.cin, cout = L.cout, T = L.ks * L.ks;
     const int coutp = ((cout + 31) / 32) * 32;         // the 32 -> 2 last layer is padded with zero rows
     const int CC = NS == 1 ? 32 : 16, nch = cin / CC;
     const float *W = w->conv_w[li];
     float mx = 0.f;
-    for (size_t i = 0; i < (size_t)cout * cin * T; ++i) mx = fmaxf(mx, fabsf(W[i]));
+    for (int co = 0; co < cout; ++co)
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < T; ++t)
+                mx = fmaxf(mx, fabsf(W[((size_t)co * cin + c) * T + t] * (cin_scale ? cin_scale[c] : 1.f)));
     int e = 0;
     if (mx > 0.f) { (void)frexpf(mx, &e); }             // mx = m 2^e, m in [0.5, 1)
     int sexp = 14 - e;
@@ -791,15 +799,15 @@ static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS) {
                     for (int co = 0; co < cout; ++co)
                         for (int e8 = 0; e8 < 8; ++e8) {
                             const int c = NS == 1 ? ch * 32 + j * 16 + hh * 8 + e8 : ch * 16 + hh * 8 + e8;
-                            const float x = W[((size_t)co * cin + c) * T + t] * sc;
+                            const float x = W[((size_t)co * cin + c) * T + t] * (cin_scale ? cin_scale[c] : 1.f) * sc;
                             const _Float16 xh = (_Float16)x;
                             const _Float16 v = (NS == 1 || j == 0) ? xh : (_Float16)(x - (float)xh);
                             pw[(((((size_t)ch * T + t) * 2 + j) * 2 + hh) * coutp + co) * 8 + e8] = v;
                         }
-    void *&dst = L.wh[NS - 1];
+    void *&dst = cin_scale ? L.whF : L.wh[NS - 1];
     QGX_HIP(hipMalloc(&dst, pw.size() * sizeof(_Float16)));
     QGX_HIP(hipMemcpy(dst, pw.data(), pw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    L.wh_unscale[NS - 1] = ldexpf(1.f, -sexp);
+    (cin_scale ? L.whF_unscale : L.wh_unscale[NS - 1]) = ldexpf(1.f, -sexp);
     return QGX_OK;
 }
 
@@ -864,6 +872,10 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
     if (planar_in) {
         if ((rc = pack_weights(L, li, w, true, L.cin, L.w))) return rc;
         if ((rc = pack_half_first(L, w))) return rc;
+        {
+            std::vector<float> o1(L.coutp, 1.f), z0(L.coutp, 0.f);
+            if ((rc = upf(L.ones, o1)) || (rc = upf(L.zeros, z0))) return rc;
+        }
     } else {
         if ((rc = pack_weights(L, li, w, false, 16, L.w))) return rc;
         if ((rc = pack_weights(L, li, w, false, 32, L.w32))) return rc;
@@ -885,6 +897,23 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
         if (li < 7) {
             if ((rc = pack_half(L, li, w, 1)) || (rc = pack_half(L, li, w, 2))) return rc;
             if (li == 1 && (rc = pack_half16(L, li, w))) return rc;
+            if (li == 1) {
+                // fold layer 1's BatchNorm (alpha, beta' of its 128 output channels) into this layer
+                const int cin = L.cin, T = L.ks * L.ks;
+                std::vector<float> al(cin), be(cin), bf(L.coutp, 0.f);
+                for (int c = 0; c < cin; ++c) {
+                    const float invstd = 1.0f / sqrtf(w->bn_var[0][c] + w->bn_eps);
+                    al[c] = w->bn_gamma[0][c] * invstd;
+                    be[c] = w->bn_beta[0][c] - w->bn_mean[0][c] * al[c];
+                }
+                for (int co = 0; co < cout; ++co) {
+                    double acc = w->conv_b[li][co];
+                    for (int c = 0; c < cin; ++c)
+                        for (int t = 0; t < T; ++t) acc += (double)w->conv_w[li][((size_t)co * cin + c) * T + t] * be[c];
+                    bf[co] = (float)acc;
+                }
+                if ((rc = pack_half(L, li, w, 2, al.data())) || (rc = upf(L.biasF, bf))) return rc;
+            }
         } else if ((rc = pack_half(L, li, w, 2))) return rc;      // fused (layer 7, layer 8) pair
     }
     if (li == 7) {      // [tap][c][2] for the VALU last-layer kernel
@@ -1446,8 +1475,16 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         const int Bc = B - b0 < mc ? B - b0 : mc;
         const float *xc = x + (size_t)b0 * net.n_in * N * N;
         float *yc = y + (size_t)b0 * net.n_out * N * N;
+        // "fold": layer 1 stores its ReLU output (identity BatchNorm in the epilogue; 50 % exact zeros with the
+        // shipped weights) and layer 2 uses the weights / bias with that BatchNorm folded in
+        const bool fold = NS == 2 && g->opt_first_h && g->opt_fold && net.L[1].whF;
+        LayerHost L0 = net.L[0], L1 = net.L[1];
+        if (fold) {
+            L0.scale = L0.ones; L0.shift = L0.zeros;
+            L1.wh[1] = L1.whF; L1.wh_unscale[1] = L1.whF_unscale; L1.bias = L1.biasF; L1.wh16 = nullptr;
+        }
         if (NS == 2 && g->opt_first_h) {
-            rc = net.n_in == 4 ? launch_convh_first<4>(g, net.L[0], xc, A, Bc, N, st) : launch_convh_first<2>(g, net.L[0], xc, A, Bc, N, st);
+            rc = net.n_in == 4 ? launch_convh_first<4>(g, L0, xc, A, Bc, N, st) : launch_convh_first<2>(g, L0, xc, A, Bc, N, st);
         } else if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         if (rc) return rc;
@@ -1456,10 +1493,10 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         const int r2 = rows_h2(N);
         const bool tiny = NS == 2 && g->opt_h2 == 3 && r2 > 0 && Bc * (N / r2) < g->opt_part_max_tiles;
         bool done1 = false;
-        if (tiny && (rc = launch_convh2_part<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
-        if (!done1 && NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
-        if (!done1 && NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, net.L[1], A, Bb, Bc, N, st, done1))) return rc;
-        if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, net.L[1], A, Bb, Bc, N, st))) return rc;
+        if (tiny && (rc = launch_convh2_part<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, L1, A, Bb, Bc, N, st))) return rc;
         if (tiny) {
             bool done2 = false;
             if ((rc = launch_convh2_part<64, 32, 3, false>(g, 2, net.L[2], Bb, A, Bc, N, st, done2))) return rc;
@@ -1631,6 +1668,8 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             for (void *p : L.wh) if (p) (void)hipFree(p);
             if (L.whf) (void)hipFree(L.whf);
             if (L.wh16) (void)hipFree(L.wh16);
+            if (L.whF) (void)hipFree(L.whF);
+            for (float *p : {L.biasF, L.ones, L.zeros}) if (p) (void)hipFree(p);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
     for (float *p : bufs) if (p) (void)hipFree(p);
@@ -1689,6 +1728,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "h3")) g->opt_h3 = value ? 1 : 0;
     else if (!strcmp(name, "last_rows")) g->opt_last_rows = value;
     else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;
+    else if (!strcmp(name, "fold")) g->opt_fold = value ? 1 : 0;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
