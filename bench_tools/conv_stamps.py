@@ -33,5 +33,11 @@ s = s[s[:, 0] > 0]
 for wg in (0, 1, len(s) // 2, len(s) - 1):
     t = s[wg][s[wg] > 0]
     print(f'wg {wg}: {len(t)} stamps over {t[-1] - t[0]} cycles; deltas: ' + ' '.join(str(v) for v in np.diff(t)))
-t0 = s[:, 0].min()
-print(f'{len(s)} workgroups; start skew {s[:, 0].max() - t0} cycles')
+if os.environ.get('QGX_STAMPS_REALTIME'):
+    # library built with -DQGX_STAMPS_REALTIME: 100 MHz counter shared by the whole chip
+    last = np.array([r[r > 0][-1] for r in s])
+    t0 = s[:, 0].min()
+    st = (s[:, 0] - t0) * 0.01
+    en = (last - t0) * 0.01
+    print(f'start after the first workgroup (us): median {np.median(st):.1f} p90 {np.percentile(st, 90):.1f} max {st.max():.1f}')
+    print(f'end after the first start (us): min {en.min():.1f} median {np.median(en):.1f} max {en.max():.1f}; lifetime median {np.median(en - st):.1f}')

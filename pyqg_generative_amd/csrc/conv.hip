@@ -692,7 +692,7 @@ struct LayerHost {
     float wh_unscale[2] = {1.f, 1.f};        // 2^-s of the power-of-two weight pre-scale
     // layer 2 with layer 1's BatchNorm folded in (W' = W alpha[c_in], b' = b + sum W beta'[c_in]; exact under circular
     // padding): layer 1 then stores ReLU output, half of which is exactly zero -> a sparser MFMA operand
-    void *whF = nullptr; float whF_unscale = 1.f; float *biasF = nullptr;
+    void *whF = nullptr, *wh16F = nullptr; float whF_unscale = 1.f; float *biasF = nullptr;
     float *ones = nullptr, *zeros = nullptr; // layer 1: identity BatchNorm for the folded variant
     void *wh16 = nullptr;                    // k_convh3 (16x16x32 MFMA): [chunk32][tap][part][octet][cout][8] f16
     void *whf = nullptr;                     // first layer, f16x3: [step][part][h][128][8] f16
@@ -719,6 +719,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_h2_grid = 0;           // k_convh2: persistent workgroups per launch (0 = one or two per CU by LDS size)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
     int opt_part_max_tiles = 112;  // f16x3: split K on the wide layers below this many tiles (crossover: 7 members at 64x64)
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
@@ -812,10 +813,10 @@ static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS, con
 }
 
 // k_convh3 layout: 32-channel chunks, [chunk][tap][part][octet][cout][8]; same power-of-two pre-scale as wh[1]
-static int pack_half16(LayerHost &L, int li, const qgx_cnn_weights *w) {
+static int pack_half16(LayerHost &L, int li, const qgx_cnn_weights *w, const float *cin_scale = nullptr) {
     const int cin = L.cin, cout = L.cout, T = L.ks * L.ks, nch = cin / 32;
     const float *W = w->conv_w[li];
-    const float sc = 1.0f / L.wh_unscale[1];
+    const float sc = 1.0f / (cin_scale ? L.whF_unscale : L.wh_unscale[1]);
     std::vector<_Float16> pw((size_t)nch * T * 2 * 4 * cout * 8, (_Float16)0.f);
     for (int ch = 0; ch < nch; ++ch)
         for (int t = 0; t < T; ++t)
@@ -824,13 +825,14 @@ static int pack_half16(LayerHost &L, int li, const qgx_cnn_weights *w) {
                     for (int co = 0; co < cout; ++co)
                         for (int e8 = 0; e8 < 8; ++e8) {
                             const int c = ch * 32 + o * 8 + e8;
-                            const float x = W[((size_t)co * cin + c) * T + t] * sc;
+                            const float x = W[((size_t)co * cin + c) * T + t] * (cin_scale ? cin_scale[c] : 1.f) * sc;
                             const _Float16 xh = (_Float16)x;
                             pw[(((((size_t)ch * T + t) * 2 + part) * 4 + o) * cout + co) * 8 + e8] =
                                 part == 0 ? xh : (_Float16)(x - (float)xh);
                         }
-    QGX_HIP(hipMalloc(&L.wh16, pw.size() * sizeof(_Float16)));
-    QGX_HIP(hipMemcpy(L.wh16, pw.data(), pw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    void *&dst16 = cin_scale ? L.wh16F : L.wh16;
+    QGX_HIP(hipMalloc(&dst16, pw.size() * sizeof(_Float16)));
+    QGX_HIP(hipMemcpy(dst16, pw.data(), pw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     return QGX_OK;
 }
 
@@ -913,6 +915,7 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
                     bf[co] = (float)acc;
                 }
                 if ((rc = pack_half(L, li, w, 2, al.data())) || (rc = upf(L.biasF, bf))) return rc;
+                if ((rc = pack_half16(L, li, w, al.data()))) return rc;
             }
         } else if ((rc = pack_half(L, li, w, 2))) return rc;      // fused (layer 7, layer 8) pair
     }
@@ -1246,6 +1249,7 @@ static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, cons
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (NN / R);
     int grid = lds * 2 <= 160 * 1024 ? 512 : 256;
+    if (g->opt_h2_grid > 0) grid = g->opt_h2_grid;
     if (grid > total_tiles) grid = total_tiles;
     constexpr bool TWO = lds * 2 <= 160 * 1024 && MT == 2;        // two workgroups per CU: <= 256 registers
     auto kern = g->opt_pair && KS == 3 ? k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO, KS == 3>
@@ -1481,7 +1485,7 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         LayerHost L0 = net.L[0], L1 = net.L[1];
         if (fold) {
             L0.scale = L0.ones; L0.shift = L0.zeros;
-            L1.wh[1] = L1.whF; L1.wh_unscale[1] = L1.whF_unscale; L1.bias = L1.biasF; L1.wh16 = nullptr;
+            L1.wh[1] = L1.whF; L1.wh_unscale[1] = L1.whF_unscale; L1.bias = L1.biasF; L1.wh16 = L1.wh16F;
         }
         if (NS == 2 && g->opt_first_h) {
             rc = net.n_in == 4 ? launch_convh_first<4>(g, L0, xc, A, Bc, N, st) : launch_convh_first<2>(g, L0, xc, A, Bc, N, st);
@@ -1669,6 +1673,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             if (L.whf) (void)hipFree(L.whf);
             if (L.wh16) (void)hipFree(L.wh16);
             if (L.whF) (void)hipFree(L.whF);
+            if (L.wh16F) (void)hipFree(L.wh16F);
             for (float *p : {L.biasF, L.ones, L.zeros}) if (p) (void)hipFree(p);
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
@@ -1729,6 +1734,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "last_rows")) g->opt_last_rows = value;
     else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;
     else if (!strcmp(name, "fold")) g->opt_fold = value ? 1 : 0;
+    else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }

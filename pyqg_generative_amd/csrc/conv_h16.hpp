@@ -19,7 +19,8 @@
 // buffering of both operand streams and for the 17 + 10 prefetch registers).
 //
 // RESULT (in-process A/B, bench_tools/ab_conv.py, option "h3"): 576-643 us against 553-584 us for the
-// 32x32x16 kernel k_convh2 on the same device — the microbenchmark's advantage does not survive in the
+// 32x32x16 kernel k_convh2 on the same device (537 against 510 us after both got the spread prefetch loads
+// and the BatchNorm fold) — the microbenchmark's advantage does not survive in the
 // full kernel (both sit at the same power-limited rate), so this kernel is OFF by default and kept as
 // the record of that experiment.
 #pragma once
@@ -65,6 +66,27 @@ __global__ __launch_bounds__(256) void k_convh3(ConvHArgs a, int total_tiles) {
             V[u] = *reinterpret_cast<const f32x4 *>(                                                        \
                 inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 128 + un_ * 16);                   \
         }                                                                                                   \
+    }
+#define QGX_H3P_LOAD1(TI, CH, V, U)                                                                         \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        int it_ = (U) * NTHR + threadIdx.x;                                                                  \
+        it_ = it_ < PU ? it_ : PU - 1;                                                                      \
+        const int un_ = it_ & 7, pl_ = it_ >> 3;                                                            \
+        const int pr_ = pl_ / PW, xx_ = pl_ - pr_ * PW;                                                     \
+        int gy_ = y0_ - P + pr_, gx_ = xx_ - P;                                                             \
+        gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                               \
+        gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                               \
+        V[U] = *reinterpret_cast<const f32x4 *>(                                                            \
+            inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 128 + un_ * 16);                       \
+    }
+#define QGX_H3W_LOAD1(CH, SL, V, U)                                                                         \
+    {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(wb + ((size_t)(CH) * NSL + (SL)) * WSB);        \
+        const int it_ = (U) * NTHR + threadIdx.x;                                                            \
+        V[U] = src_[it_ < WU ? it_ : WU - 1];                                                               \
     }
 #define QGX_H3P_STORE(V)                                                                                    \
     {                                                                                                       \
@@ -125,16 +147,15 @@ __global__ __launch_bounds__(256) void k_convh3(ConvHArgs a, int total_tiles) {
             const int nti = ch + 1 < NCH ? ti : ti + 1;
             const bool have_next_chunk = nti < n_my;
             f32x4 pv[PPT];
-            QGX_H3P_LOAD(have_next_chunk ? nti : ti, have_next_chunk ? nch : ch, pv)
+            const int p_ti = have_next_chunk ? nti : ti, p_ch = have_next_chunk ? nch : ch;
 #pragma unroll
             for (int sl = 0; sl < NSL; ++sl) {
                 f32x4 wv[WPT];
                 const bool last_stage = !have_next_chunk && sl == NSL - 1;
-                {
-                    const int wch = sl + 1 < NSL ? ch : (have_next_chunk ? nch : ch);
-                    const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
-                    QGX_H3W_LOAD(wch, wsl, wv)
-                }
+                // global prefetch loads spread over the first taps of the stage (see k_convh2)
+                const int wch = sl + 1 < NSL ? ch : (have_next_chunk ? nch : ch);
+                const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
+                const int n_ld = WPT + (sl == 0 ? PPT : 0);
                 h8 Pn[4][2], Wn[4][2];
 #define QGX_H3_FRAGS(TL)                                                                                    \
                 {                                                                                           \
@@ -163,6 +184,13 @@ __global__ __launch_bounds__(256) void k_convh3(ConvHArgs a, int total_tiles) {
 #pragma unroll
                             for (int j = 0; j < 2; ++j)
                                 Wn[cg][j] = *reinterpret_cast<const h8 *>(wl + tln * TAPB + j * (4 * COUT * 16) + cg * 256);
+                    }
+#pragma unroll
+                    for (int i = 0; i < WPT + PPT; ++i) {
+                        if (i < n_ld && (i * (TPS - 1)) / n_ld == tl) {
+                            if (i < WPT) { QGX_H3W_LOAD1(wch, wsl, wv, i) }
+                            else { QGX_H3P_LOAD1(p_ti, p_ch, pv, i - WPT) }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -245,6 +273,8 @@ __global__ __launch_bounds__(256) void k_convh3(ConvHArgs a, int total_tiles) {
         }
     }
 #undef QGX_H3P_LOAD
+#undef QGX_H3P_LOAD1
+#undef QGX_H3W_LOAD1
 #undef QGX_H3P_STORE
 #undef QGX_H3W_LOAD
 #undef QGX_H3W_STORE

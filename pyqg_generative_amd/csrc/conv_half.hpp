@@ -46,8 +46,13 @@ struct ConvHArgs {
 };
 
 #ifdef QGX_STAMPS
+#ifdef QGX_STAMPS_REALTIME      // 100 MHz, the same counter on every XCD: workgroup start / end skew across the chip
+#define QGX_STAMP_CLOCK __builtin_amdgcn_s_memrealtime
+#else                           // shader-clock cycles, comparable only within one CU
+#define QGX_STAMP_CLOCK __builtin_amdgcn_s_memtime
+#endif
 #define QGX_STAMP()                                                                          \
-    if (a.stamps && threadIdx.x == 0 && stamp_i < 64) a.stamps[blockIdx.x * 64 + stamp_i++] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && threadIdx.x == 0 && stamp_i < 64) a.stamps[blockIdx.x * 64 + stamp_i++] = QGX_STAMP_CLOCK();
 #else
 #define QGX_STAMP()
 #endif
@@ -502,8 +507,13 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
     f32x16 acc[MT][NT];
     int cur_w = 0;
     for (int ti = 0; ti < n_my; ++ti) {
-#pragma unroll(PAIR ? NCH : 1)
-        for (int ch = cbeg; ch < cend; ++ch) {
+        // PAIR: a run-time loop over chunk pairs with the two chunks of a pair unrolled (the parity decides
+        // which prefetch set is loaded / stored, so it has to be a compile-time constant)
+        for (int cp = cbeg; cp < cend; cp += (PAIR ? 2 : 1))
+#pragma unroll
+        for (int ci = 0; ci < (PAIR ? 2 : 1); ++ci) {
+            const int ch = cp + ci;
+            const bool odd = ci == 1;
             if (ch == cbeg) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                 const bool last_stage = !have_next_chunk && sl == NSL - 1;
                 const int wch = sl + 1 < NSL ? ch : (have_next_chunk ? nch : ch);
                 const int wsl = sl + 1 < NSL ? sl + 1 : (have_next_chunk ? 0 : sl);
-                const int n_pl = PAIR ? ((ch & 1) ? 2 * PPT : 0) : (sl == 0 ? PPT : 0);   // patch loads of this stage
+                const int n_pl = PAIR ? (odd ? 2 * PPT : 0) : (sl == 0 ? PPT : 0);   // patch loads of this stage
                 const int n_ld = WPT + n_pl;
                 constexpr int TSPREAD = TPS > 2 ? TPS - 1 : TPS;                       // the last tap carries none
                 const char *wl = wlds0 + (WDB ? cur_w * WSB : 0) + wofs;
@@ -598,7 +608,7 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
                         __syncthreads();
                         QGX_STAMP()
                         if constexpr (PAIR) {
-                            if (ch & 1) { if (have_next_chunk) QGX_H2P_STORE(pvA) } else QGX_H2P_STORE(pvB)
+                            if (odd) { if (have_next_chunk) QGX_H2P_STORE(pvA) } else QGX_H2P_STORE(pvB)
                         } else {
                             if (have_next_chunk) QGX_H2P_STORE(pv)
                         }
