@@ -78,16 +78,16 @@ __device__ __forceinline__ void build_uv(double2 *Z, const Grid &g, const SpecDe
     }
 }
 
-// Build the packed spectrum of (A + i B) from two half spectra in global memory.
+// Build the packed spectrum of (A + i B) from two half spectra in global memory (Bh == nullptr: B = 0).
 __device__ __forceinline__ void build_pair(double2 *Z, const Grid &g, const double2 *Ah,
                                            const double2 *Bh, double scale) {
     const int N = g.N, NK = g.NK;
     for (int idx = threadIdx.x; idx < N * NK; idx += blockDim.x) {
         const int j = idx / NK, i = idx - j * NK;
-        double2 a = Ah[idx], b = Bh[idx];
+        double2 a = Ah[idx], b = Bh ? Bh[idx] : make_double2(0., 0.);
         if (i == 0 || 2 * i == N) {
             const int idm = neg_mod(j, N) * NK + i;
-            const double2 am = Ah[idm], bm = Bh[idm];
+            const double2 am = Ah[idm], bm = Bh ? Bh[idm] : make_double2(0., 0.);
             a = make_double2(0.5 * (a.x + am.x), 0.5 * (a.y - am.y));
             b = make_double2(0.5 * (b.x + bm.x), 0.5 * (b.y - bm.y));
         }
@@ -107,14 +107,21 @@ __device__ __forceinline__ Grid make_grid(const SpecDev &d, double2 *Z, int *&po
 extern __shared__ __attribute__((aligned(16))) char qgx_smem[];
 
 // ------------------------------------------------------------------ one time step
-template <int NN>
+// LSPLIT: two workgroups per member, one per layer.  Nothing couples the layers inside a step except the
+// inversion (both workgroups read both layers of qh_in), so workgroup k runs the chain of layer k only:
+// forcing S_k, (u_k, v_k), advection of layer k, its tendency and AB3 update, q_k — four 2-D FFTs instead
+// of six, with the single real fields packed as (x + 0 i).  Used while 2B workgroups are all resident
+// (the kernel is a latency chain then: B = 128 at 64x64 leaves half of the CUs idle with one workgroup per
+// member); 8 FFTs per member instead of 6 make it slower once members queue up.
+template <int NN, bool LSPLIT = false>
 __global__ void k_step_small(SpecDev d, StepArgs a) {
     double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
     int *pos_lds;
     Grid g = make_grid(d, Z, pos_lds);
     if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
     const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD;
-    const int b = blockIdx.x;
+    const int b = LSPLIT ? blockIdx.x >> 1 : blockIdx.x;
+    const int kown = LSPLIT ? blockIdx.x & 1 : 0;
     const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
     const int sz = N * NK, rz = N * N;
     const double2 *qh0 = a.qh_in + so, *qh1 = qh0 + sz;
@@ -125,7 +132,8 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
         const double *S0 = a.S + ro, *S1 = S0 + rz;
         for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
             const int y = idx / N, x = idx - y * N;
-            Z[y * LD + x] = make_double2(a.weight * S0[idx], a.weight * S1[idx]);
+            if (LSPLIT) Z[y * LD + x] = make_double2(a.weight * (kown ? S1 : S0)[idx], 0.);
+            else Z[y * LD + x] = make_double2(a.weight * S0[idx], a.weight * S1[idx]);
         }
         __syncthreads();
         fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
@@ -134,13 +142,17 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
             double2 s0, s1;
             unpack_pair(Z, g, j, i, s0, s1);
             if (a.demean && idx == 0) { s0 = make_double2(0., 0.); s1 = s0; }
-            a.dqh[so + idx] = s0;
-            a.dqh[so + sz + idx] = s1;
+            if (LSPLIT) {
+                a.dqh[so + kown * sz + idx] = s0;
+            } else {
+                a.dqh[so + idx] = s0;
+                a.dqh[so + sz + idx] = s1;
+            }
         }
         __syncthreads();
     }
 
-    for (int k = 0; k < 2; ++k) {
+    for (int k = kown; k < (LSPLIT ? kown + 1 : 2); ++k) {
         // ---- _invert: ph_k, (u_k, v_k) = irfft2(-il ph, ik ph)
         build_uv(Z, g, d, k, qh0, qh1, a.diag ? a.ph + so + k * sz : nullptr);
         __syncthreads();
@@ -191,15 +203,20 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
         }
         __syncthreads();
     }
-    // ---- q^{n+1} = irfft2(qh^{n+1}), both layers packed
-    build_pair(Z, g, a.qh_out + so, a.qh_out + so + sz, d.invN2);
+    // ---- q^{n+1} = irfft2(qh^{n+1}), both layers packed (LSPLIT: the own layer alone)
+    if (LSPLIT) build_pair(Z, g, a.qh_out + so + kown * sz, nullptr, d.invN2);
+    else build_pair(Z, g, a.qh_out + so, a.qh_out + so + sz, d.invN2);
     __syncthreads();
     fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
     for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
         const int y = idx / N, x = idx - y * N;
         const double2 w = Z[y * LD + x];
-        a.q[ro + idx] = w.x;
-        a.q[ro + rz + idx] = w.y;
+        if (LSPLIT) {
+            a.q[ro + kown * rz + idx] = w.x;
+        } else {
+            a.q[ro + idx] = w.x;
+            a.q[ro + rz + idx] = w.y;
+        }
     }
 }
 
@@ -309,6 +326,7 @@ int small_prepare(const SpecDev &d) {
     const int bytes = (int)small_lds_bytes(d);
     QGX_DISPATCH_N(d.N, {
         QGX_HIP(hipFuncSetAttribute((const void *)k_step_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_q_to_qh_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_qh_to_q_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -316,8 +334,19 @@ int small_prepare(const SpecDev &d) {
     return QGX_OK;
 }
 
+// two workgroups per member (one per layer) while all of them are resident at once
+static bool layer_split(const SpecDev &d) {
+    static const int forced = getenv("QGX_SPEC_LSPLIT") ? atoi(getenv("QGX_SPEC_LSPLIT")) : -1;   // tuning aid
+    if (forced >= 0) return forced != 0;
+    return 2 * d.B <= 256;      // one workgroup per CU (measured at 64x64: B = 128 44 -> 33 us, B = 256 55 -> 63 us)
+}
+
 int small_step(const SpecDev &d, const StepArgs &a, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_step_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, a))
+    if (layer_split(d)) {
+        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
+    } else {
+        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_step_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, a))
+    }
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
