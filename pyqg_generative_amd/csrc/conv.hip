@@ -545,7 +545,9 @@ __global__ void k_conv_reduce(const float *partial, int nsplit, size_t npix_tota
 // pixel run at full useful rate: one thread per pixel, weights broadcast from scalar registers.
 struct LastWeights { float w[3 * 3 * 32 * 2]; };   // [tap][c][2], passed BY VALUE: kernarg -> scalar loads
 
-template <int CIN, int KS>
+// PARTS = 4 (single-row tiles of 64 pixels, i.e. one or two members at 64 x 64): the four waves split the input
+// channels of the same 64 pixels and combine through LDS — a 4x shorter dependent FMA chain per thread
+template <int CIN, int KS, int PARTS = 1>
 __global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
     constexpr int P = KS / 2, STRIDE = CIN + 4, C4 = CIN / 4;
     float *patch = reinterpret_cast<float *>(conv_smem);
@@ -564,7 +566,10 @@ __global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
     }
     __syncthreads();
     const float *w = lw.w;
-    for (int p = threadIdx.x; p < R * N; p += 256) {
+    const int part = PARTS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;   // wave-uniform
+    constexpr int CPP = C4 / PARTS;                    // float4 channel groups per part
+    float *red = patch + PR * N * STRIDE;              // PARTS > 1: [part][pixel][2]
+    for (int p = PARTS > 1 ? (threadIdx.x & 63) : threadIdx.x; p < R * N; p += PARTS > 1 ? 64 : 256) {
         const int py = p / N, px = p - py * N;
         float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll 1
@@ -573,10 +578,10 @@ __global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
             for (int kx = 0; kx < KS; ++kx) {
                 int col = px + kx - P;
                 col = col < 0 ? col + N : (col >= N ? col - N : col);
-                const float *src = &patch[((py + ky) * N + col) * STRIDE];
-                const float *wt = w + (ky * KS + kx) * CIN * 2;
+                const float *src = &patch[((py + ky) * N + col) * STRIDE + part * CPP * 4];
+                const float *wt = w + ((ky * KS + kx) * CIN + part * CPP * 4) * 2;
 #pragma unroll
-                for (int c4 = 0; c4 < C4; ++c4) {
+                for (int c4 = 0; c4 < CPP; ++c4) {
                     const float4 v = *reinterpret_cast<const float4 *>(src + c4 * 4);
                     acc0 = fmaf(v.x, wt[(c4 * 4 + 0) * 2], acc0); acc1 = fmaf(v.x, wt[(c4 * 4 + 0) * 2 + 1], acc1);
                     acc0 = fmaf(v.y, wt[(c4 * 4 + 1) * 2], acc0); acc1 = fmaf(v.y, wt[(c4 * 4 + 1) * 2 + 1], acc1);
@@ -584,9 +589,24 @@ __global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
                     acc0 = fmaf(v.w, wt[(c4 * 4 + 3) * 2], acc0); acc1 = fmaf(v.w, wt[(c4 * 4 + 3) * 2 + 1], acc1);
                 }
             }
-        float *o = a.out + (size_t)b * a.cout_real * N * N + (size_t)y0 * N + p;
-        o[0] = acc0 + a.bias[0];
-        if (a.cout_real > 1) o[(size_t)N * N] = acc1 + a.bias[1];
+        if constexpr (PARTS > 1) {
+            red[(part * 64 + p) * 2] = acc0;
+            red[(part * 64 + p) * 2 + 1] = acc1;
+        } else {
+            float *o = a.out + (size_t)b * a.cout_real * N * N + (size_t)y0 * N + p;
+            o[0] = acc0 + a.bias[0];
+            if (a.cout_real > 1) o[(size_t)N * N] = acc1 + a.bias[1];
+        }
+    }
+    if constexpr (PARTS > 1) {
+        __syncthreads();
+        const int p = threadIdx.x >> 1, c = threadIdx.x & 1;
+        if (p < R * N && c < a.cout_real) {
+            float v = a.bias[c];
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) v += red[(q * 64 + p) * 2 + c];   // fixed order
+            a.out[((size_t)b * a.cout_real + c) * N * N + (size_t)y0 * N + p] = v;
+        }
     }
 }
 
@@ -640,8 +660,8 @@ __global__ void k_prep_noise(const double *q, float *z, const float *xi_ext, flo
 //   GZ:      S = (mean + z sqrt(softplus(var))) * y_std    (mean_var_model.py:14-17,105-109)
 //   then S -= mean_{y,x} S                                 (parameterization.py:25)
 template <bool GZ>
-__global__ void k_finish(const float *y0, const float *y1, const double *z, double *S, int npix, float ys0,
-                         float ys1, int demean) {
+__global__ __launch_bounds__(1024) void k_finish(const float *y0, const float *y1, const double *z, double *S, int npix, float ys0,
+                                                 float ys1, int demean) {
     __shared__ double sm[16];
     __shared__ double mean_s;
     const size_t o = (size_t)blockIdx.x * npix;
@@ -655,10 +675,24 @@ __global__ void k_finish(const float *y0, const float *y1, const double *z, doub
             return (double)(y0[o + i] * ys);
         }
     };
+    // one workgroup per (member, layer) is a short latency chain: 1024 threads, and the values are read ONCE
+    // (kept in registers between the mean and the store for grids up to 128 x 128)
+    constexpr int KEEP = 16;
+    double keep[KEEP];
+    const bool cached = npix <= KEEP * (int)blockDim.x;
+    double acc = 0.0;
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const int i = u * blockDim.x + threadIdx.x;
+            keep[u] = i < npix ? value(i) : 0.0;
+            acc += keep[u];
+        }
+    } else if (demean) {
+        for (int i = threadIdx.x; i < npix; i += blockDim.x) acc += value(i);
+    }
     double mu = 0.0;
     if (demean) {
-        double acc = 0.0;
-        for (int i = threadIdx.x; i < npix; i += blockDim.x) acc += value(i);
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
         __syncthreads();
@@ -670,7 +704,15 @@ __global__ void k_finish(const float *y0, const float *y1, const double *z, doub
         __syncthreads();
         mu = mean_s;
     }
-    for (int i = threadIdx.x; i < npix; i += blockDim.x) S[o + i] = value(i) - mu;
+    if (cached) {
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u) {
+            const int i = u * blockDim.x + threadIdx.x;
+            if (i < npix) S[o + i] = keep[u] - mu;
+        }
+    } else {
+        for (int i = threadIdx.x; i < npix; i += blockDim.x) S[o + i] = value(i) - mu;
+    }
 }
 
 // running first and second moments over Monte-Carlo samples (generate_mean_var, cgan_regression.py:139-146)
@@ -1138,11 +1180,18 @@ static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *i
     ConvArgs a = {};
     a.in = in; a.out = out; a.w = nullptr; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = n_out;
-    const size_t lds = (size_t)(R + 2) * N * 36 * sizeof(float);
+    const bool split = R * N == 64;                        // one wave of pixels: the waves split the channels
+    const size_t lds = (size_t)(R + 2) * N * 36 * sizeof(float) + (split ? 4 * 64 * 2 * sizeof(float) : 0);
     QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
-    auto kern = k_conv_last<32, 3>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(B * (N / R)), dim3(256), lds, st, a, L.wv_host);
+    if (split) {
+        auto kern = k_conv_last<32, 3, 4>;
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(B * (N / R)), dim3(256), lds, st, a, L.wv_host);
+    } else {
+        auto kern = k_conv_last<32, 3>;
+        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(B * (N / R)), dim3(256), lds, st, a, L.wv_host);
+    }
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
@@ -1605,7 +1654,7 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
         hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)nullptr, g->X, 2, npix, g->x_std[0], g->x_std[1]);
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
         if ((rc = cnn_forward(g, g->nets[1], g->X, g->Y1, B, N, st))) return rc;
-        hipLaunchKernelGGL(k_finish<true>, dim3(2 * B), dim3(256), 0, st, (const float *)g->Y0, (const float *)g->Y1,
+        hipLaunchKernelGGL(k_finish<true>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)g->Y1,
                            (const double *)z, S, npix, g->y_std[0], g->y_std[1], demean);
     } else {
         if (nu) {
@@ -1617,7 +1666,7 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
             hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)z, g->X, 4, npix, g->x_std[0], g->x_std[1]);
         }
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
-        hipLaunchKernelGGL(k_finish<false>, dim3(2 * B), dim3(256), 0, st, (const float *)g->Y0, (const float *)nullptr,
+        hipLaunchKernelGGL(k_finish<false>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)nullptr,
                            (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean);
     }
     QGX_HIP(hipGetLastError());
