@@ -78,6 +78,27 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
                 inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 64 + un_ * 16);                    \
         }                                                                                                   \
     }
+#define QGX_PP_LOAD1(TI, CH, V, U)                                                                          \
+    {                                                                                                       \
+        const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
+        const int b_ = tile_ / tiles_per_img;                                                               \
+        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        int it_ = (U) * NTHR + threadIdx.x;                                                                  \
+        it_ = it_ < PU ? it_ : PU - 1;                                                                      \
+        const int un_ = it_ & 3, pl_ = it_ >> 2;                                                            \
+        const int pr_ = pl_ / PW, xx_ = pl_ - pr_ * PW;                                                     \
+        int gy_ = y0_ - 2 + pr_, gx_ = xx_ - 1;                                                             \
+        gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                               \
+        gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                               \
+        V[U] = *reinterpret_cast<const f32x4 *>(                                                            \
+            inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 64 + un_ * 16);                        \
+    }
+#define QGX_PW_LOAD1(CH, V, U)                                                                              \
+    {                                                                                                       \
+        const f32x4 *src_ = reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(a.wA) + (size_t)(CH) * WSLICE); \
+        const int it_ = (U) * NTHR + threadIdx.x;                                                            \
+        V[U] = src_[it_ < WU ? it_ : WU - 1];                                                               \
+    }
 #define QGX_PP_STORE(V)                                                                                     \
     {                                                                                                       \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
@@ -149,8 +170,8 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
 #pragma unroll
         for (int ch = 0; ch < NCA; ++ch) {
             f32x4 pv[PPT], wv[WPT];
-            if (ch + 1 < NCA) QGX_PP_LOAD(ti, ch + 1, pv)
-            QGX_PW_LOAD(ch + 1 < NCA ? ch + 1 : 0, wv)
+            // the global prefetch loads of this chunk are spread over its first taps (see k_convh2)
+            const int n_ld = WPT + (ch + 1 < NCA ? PPT : 0);
             h8 Pn[MTA][2], Wn[2];
 #define QGX_PA_FRAGS(TAP)                                                                                   \
             {                                                                                               \
@@ -170,6 +191,13 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
                 for (int mt = 0; mt < MTA; ++mt) { Pc[mt][0] = Pn[mt][0]; Pc[mt][1] = Pn[mt][1]; }
                 Wc[0] = Wn[0]; Wc[1] = Wn[1];
                 if (tap + 1 < T) QGX_PA_FRAGS(tap + 1)
+#pragma unroll
+                for (int i = 0; i < WPT + PPT; ++i) {
+                    if (i < n_ld && (i * (T - 1)) / n_ld == tap) {
+                        if (i < WPT) { QGX_PW_LOAD1(ch + 1 < NCA ? ch + 1 : 0, wv, i) }
+                        else { QGX_PP_LOAD1(ti, ch + 1, pv, i - WPT) }
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MTA; ++mt) {
@@ -249,7 +277,6 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
 #pragma unroll
             for (int r = 0; r < 16; ++r) accB[mt][r] = 0.f;
         f32x4 pv[PPT];
-        QGX_PP_LOAD(have_next_tile ? ti + 1 : ti, 0, pv)
         {
             h8 Pn[MTB][2], Wn[2];
 #define QGX_PB_FRAGS(S)                                                                                     \
@@ -270,6 +297,9 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
                 for (int mt = 0; mt < MTB; ++mt) { Pc[mt][0] = Pn[mt][0]; Pc[mt][1] = Pn[mt][1]; }
                 Wc[0] = Wn[0]; Wc[1] = Wn[1];
                 if (s + 1 < 2 * T) QGX_PB_FRAGS(s + 1)
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if ((i * (2 * T - 2)) / PPT == s) QGX_PP_LOAD1(have_next_tile ? ti + 1 : ti, 0, pv, i)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MTB; ++mt) {
@@ -311,6 +341,8 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
         QGX_STAMP()
     }
 #undef QGX_PP_LOAD
+#undef QGX_PP_LOAD1
+#undef QGX_PW_LOAD1
 #undef QGX_PP_STORE
 #undef QGX_PW_LOAD
 #undef QGX_PW_STORE

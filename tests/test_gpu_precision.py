@@ -98,7 +98,7 @@ VARIANTS = [
     dict(h2=0, half_nw=8, res=1, fuse=0),        # resident-weight 3x3 kernel k_convh_res
     dict(h2=3, pair=0, fuse=0),                  # k_convh2 without the line-pair fetch
     dict(h2=3, fuse=7),                          # every 3x3 pair fused (k_convh_pair)
-    dict(h2=3, fuse=1),
+    dict(h2=3, fuse=2),
     dict(h3=1),                                  # 5x5 layer on 16x16x32 MFMAs (k_convh3)
     dict(first_h=0),                             # exact-f32 first layer writing the 16-bit layout
     dict(fold=0),                                # layer 1's BatchNorm applied in its epilogue instead of folded into layer 2
@@ -117,7 +117,7 @@ def test_optional_kernel_variants_agree(N, B):
     ref = gen.cnn_forward(x).cpu().numpy()
     gen.set_option('precision', 3)
     gen.set_option('part_max_tiles', 0)
-    defaults = dict(h2=3, half_nw=8, res=1, fuse=2, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0, fold=1)
+    defaults = dict(h2=3, half_nw=8, res=1, fuse=3, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0, fold=1)
     for v in VARIANTS:
         for k, d in defaults.items():
             gen.set_option(k, v.get(k, d))
