@@ -155,7 +155,9 @@ int main() {
         const double mfmas = mode == 2 ? 8 : (mode == 3 || mode >= 4 ? 24 : 12);
         const double flop_per = mode == 3 ? 2.0 * 16 * 16 * 32 : 2.0 * 32 * 32 * 16;
         const double flop = (double)grid * (mode == 4 ? 4 : 8) * iters * mfmas * flop_per;
-        const double cyc_per_mfma = h[0] / ((double)iters * mfmas * 2);   // 2 waves per SIMD
+        const double clock_hz = h[1] ? (double)h[0] / (double)h[1] * 1e8 : 0.0;
+        const double waves_per_simd = mode == 4 ? 1 : 2;
+        const double cyc_per_mfma = best * 1e-3 * clock_hz / ((double)iters * mfmas * waves_per_simd);
         printf("mode %d: %.3f ms  %.0f TFLOP/s (f16 MFMA)  shader clock %.0f MHz  %.1f cycles per MFMA per SIMD\n", mode, best,
                flop / best / 1e9, h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0, cyc_per_mfma);
     }
