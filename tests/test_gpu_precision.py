@@ -39,7 +39,8 @@ def _maxrel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
-@pytest.mark.parametrize('kind,N,B', [('gan', 64, 32), ('vae', 96, 24), ('gz', 48, 48), ('gan', 32, 32), ('gan', 128, 16)])
+@pytest.mark.parametrize('kind,N,B', [('gan', 64, 32), ('vae', 96, 24), ('gz', 48, 48), ('gan', 32, 32), ('gan', 128, 16),
+                                      ('gz', 64, 16), ('vae', 64, 16), ('gan', 64, 2)])
 def test_split_f16_is_float32_class(kind, N, B):
     gen = _gpu_generator(kind)
     nets = _oracle_nets(kind)
