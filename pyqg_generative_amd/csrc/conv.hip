@@ -44,6 +44,7 @@ extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 #include "conv_half.hpp"
 #include "conv_pair.hpp"
 #include "conv_h16.hpp"
+#include "conv_h4.hpp"
 
 // OUTH = 0: f32 NHWC output.  OUTH = 1 / 2 (first layer only): the MFMA roles are swapped (lane = pixel)
 // and the epilogue writes the packed f16 / f16 hi-lo activation layout of conv_half.hpp.
@@ -761,6 +762,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_h4 = 0;                // 5x5 layer: k_convh4 (full-line patch chunks, 8 waves, R = 8)
     int opt_h2_grid = 0;           // k_convh2: persistent workgroups per launch (0 = one or two per CU by LDS size)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
     int opt_part_max_tiles = 112;  // f16x3: split K on the wide layers below this many tiles (crossover: 7 members at 64x64)
@@ -1453,6 +1455,37 @@ static int launch_convh3(qgx_generator *g, int layer, const LayerHost &L, const 
     return QGX_OK;
 }
 
+// the 128 -> 64, 5x5 layer with full-line patch chunks (k_convh4: 8 waves, R = 8)
+template <int NN, int MT, int NW>
+static int launch_convh4_n(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, hipStream_t st) {
+    constexpr int R = NW * MT * 32 / NN, PR = R + 4, PW = NN + 4;
+    constexpr size_t lds = (size_t)PR * PW * 144 + (size_t)2 * 5 * 4 * 64 * 16 + 3 * 64 * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS");
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    ConvHArgs a = {};
+    a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
+    a.N = NN; a.R = R;
+    const int total_tiles = B * (NN / R);
+    int grid = 256;
+    if (grid > total_tiles) grid = total_tiles;
+    auto kern = k_convh4<NN, MT, NW>;
+    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
+}
+static int launch_convh4(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
+                         hipStream_t st, bool &done) {
+    done = true;
+    if (N == 64 && B * 8 >= 256)
+        return g->opt_h4 == 2 ? launch_convh4_n<64, 4, 4>(g, layer, L, in, out, B, st) : launch_convh4_n<64, 2, 8>(g, layer, L, in, out, B, st);
+    done = false;
+    return QGX_OK;
+}
+
 // two fused 3x3 layers (k_convh_pair); 64 x 64 grids
 template <int CINA, bool LAST, bool BOUTF32>
 static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, const LayerHost &LB, const void *in,
@@ -1547,6 +1580,7 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         const bool tiny = NS == 2 && g->opt_h2 == 3 && r2 > 0 && Bc * (N / r2) < g->opt_part_max_tiles;
         bool done1 = false;
         if (tiny && (rc = launch_convh2_part<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && NS == 2 && g->opt_h4 && (rc = launch_convh4(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, L1, A, Bb, Bc, N, st))) return rc;
@@ -1784,6 +1818,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;
     else if (!strcmp(name, "fold")) g->opt_fold = value ? 1 : 0;
     else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
+    else if (!strcmp(name, "h4")) g->opt_h4 = value;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }

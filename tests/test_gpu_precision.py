@@ -101,13 +101,14 @@ VARIANTS = [
     dict(h2=3, fuse=7),                          # every 3x3 pair fused (k_convh_pair)
     dict(h2=3, fuse=2),
     dict(h3=1),                                  # 5x5 layer on 16x16x32 MFMAs (k_convh3)
+    dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
     dict(first_h=0),                             # exact-f32 first layer writing the 16-bit layout
     dict(fold=0),                                # layer 1's BatchNorm applied in its epilogue instead of folded into layer 2
     dict(member_chunk=16),                       # member sub-batches
 ]
 
 
-@pytest.mark.parametrize('N,B', [(64, 16), (96, 8), (48, 16)])
+@pytest.mark.parametrize('N,B', [(64, 32), (96, 8), (48, 16)])
 def test_optional_kernel_variants_agree(N, B):
     """every selectable f16x3 kernel variant against the exact-f32 path: float32 tolerance (2e-5 of the
     maximum); options that do not apply to a grid size fall back to the default kernels"""
@@ -118,7 +119,7 @@ def test_optional_kernel_variants_agree(N, B):
     ref = gen.cnn_forward(x).cpu().numpy()
     gen.set_option('precision', 3)
     gen.set_option('part_max_tiles', 0)
-    defaults = dict(h2=3, half_nw=8, res=1, fuse=3, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0, fold=1)
+    defaults = dict(h2=3, half_nw=8, res=1, fuse=3, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h4=0)
     for v in VARIANTS:
         for k, d in defaults.items():
             gen.set_option(k, v.get(k, d))
