@@ -303,3 +303,37 @@ def test_fused_step_noise_follows_pinned_philox_stream():
         x1, _ = samplers_ref.philox_normal(seed, off + m, 1, 2 * N * N)
         assert np.abs(z0[m] - x0).max() < 2e-5
         assert np.abs(z1[m] - (a * x0 + b * x1)).max() < 4e-5
+
+
+def test_full_size_step_members_are_independent():
+    """BASELINE's single-GPU shard (128 members, 64 x 64, GAN): copies of four members spread over the
+    ensemble, fed the same external noise, stay bit-identical through parameterized steps, and the
+    first copies match the CPU oracle (size-independent property at the full benchmark size)."""
+    import pyqg_generative_amd._lib as L
+    N, B, nsteps = 64, 128, 3
+    rs = np.random.RandomState(11)
+    q4 = _eddy_like_q(rs, 4, N)
+    xi4 = rs.randn(nsteps, 4, 2, N, N).astype('float32')
+    gen = _gpu_generator('gan')
+    e = _engine(N, B, dt=14400.)
+    e.set_q(np.tile(q4, (B // 4, 1, 1, 1)))
+    for s in range(nsteps):
+        z = torch.as_tensor(np.tile(xi4[s], (B // 4, 1, 1, 1))).cuda()
+        e.step(1, generator=gen, sampling='constant', nsteps_decor=1, z_external=z)
+    qh = e.get(L.F_QH)
+    for r in range(4):
+        assert torch.equal(qh[r::4], qh[r:r + 1].expand(B // 4, -1, -1, -1)), r
+    ora = load_generator('gan')
+    for b in range(2):
+        it = iter(xi4[:, b])
+        class _Rng:
+            def randn(self, *shape):
+                return next(it).astype('float64').reshape(shape)
+        m = qg_ref.QGModelRef(nx=N, dt=14400.)
+        m.sampling_type = 'constant'
+        m.noise_sampler = samplers_ref.make_sampler('constant', 1)
+        m.q_parameterization = gen_ref.ParameterizationRef(ora, rng=_Rng())
+        m.set_q(q4[b])
+        for s in range(nsteps):
+            m._step_forward()
+        assert _rel(qh[b].cpu().numpy(), m.qh) < 5e-6

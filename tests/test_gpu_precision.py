@@ -134,3 +134,27 @@ def test_optional_kernel_variants_agree(N, B):
         gen.set_option('half_nw', nw)
         err = _maxrel(gen.cnn_forward(x).cpu().numpy(), ref)
         assert err < 1e-2, (nw, err)
+
+
+@pytest.mark.parametrize('kind', ['gan', 'gz'])
+def test_full_size_properties(kind):
+    """BASELINE's full single-GPU size (128 members, 64 x 64) through size-independent properties of a
+    circular convolution stack, on the default kernels (f16x3, fused pairs):
+      * members are independent: copies of a member at different positions of the ensemble give
+        bit-identical outputs (every tile / workgroup / chunk schedule computes a pixel the same way)
+      * translation equivariance: circularly shifting the input shifts the output, bit for bit
+        (a pixel's summation order does not depend on where its tile lies)"""
+    gen = _gpu_generator(kind)
+    N, B = 64, 128
+    rs = np.random.RandomState(3)
+    n_in = 2 if kind == 'gz' else 4
+    base = rs.randn(4, n_in, N, N).astype('float32')
+    x = torch.as_tensor(np.tile(base, (B // 4, 1, 1, 1)), device='cuda')
+    y = gen.cnn_forward(x)
+    for r in range(4):
+        assert torch.equal(y[r::4], y[r:r + 1].expand(B // 4, -1, -1, -1)), r
+    ref = gen_ref.cnn_forward(_oracle_nets(kind)[0], base)
+    assert _maxrel(y[:4].cpu().numpy(), ref) < 2e-5
+    for dy, dx in ((1, 0), (0, 3), (5, 7), (37, 61)):
+        ys = gen.cnn_forward(torch.roll(x, shifts=(dy, dx), dims=(2, 3)))
+        assert torch.equal(ys, torch.roll(y, shifts=(dy, dx), dims=(2, 3))), (dy, dx)
