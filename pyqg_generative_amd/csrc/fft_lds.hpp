@@ -4,7 +4,7 @@
 // digit-reversed order out.  Inverse = the transposed flow graph
 // (decimation-in-time, conjugate twiddles), digit-reversed in -> natural out.
 // Spectral-space code addresses coefficients through SpecDev::pos[], so no
-// reordering pass is ever executed.  Radices 2, 3, 4, 8.
+// reordering pass is ever executed.  Radices 2, 3, 4, 6, 8, 12.
 //
 // A "line" is one 1-D transform of length N living in LDS at
 //   base + line * line_stride + e * elem_stride      (units: double2)
@@ -66,6 +66,39 @@ __device__ __forceinline__ void small_dft(double2 (&v)[R]) {
         v[1] = cadd(e[1], t1);   v[5] = csub(e[1], t1);
         v[2] = cadd(e[2], t2);   v[6] = csub(e[2], t2);
         v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
+    } else if constexpr (R == 6) {
+        // 6 = 2 x 3, decimation in time: E = DFT3(even), O = DFT3(odd); X[k] = E[k] + W6^k O[k], X[k+3] = E[k] - W6^k O[k]
+        double2 e[3] = {v[0], v[2], v[4]}, o[3] = {v[1], v[3], v[5]};
+        small_dft<3, FWD>(e);
+        small_dft<3, FWD>(o);
+        const double s3 = 0.86602540378443864676;            // sin(pi/3)
+        // W6^1 = (1/2, -+s3), W6^2 = (-1/2, -+s3)   (upper sign: forward)
+        const double2 w1 = make_double2(0.5, FWD ? -s3 : s3), w2 = make_double2(-0.5, FWD ? -s3 : s3);
+        const double2 t1 = cmul(o[1], w1), t2 = cmul(o[2], w2);
+        v[0] = cadd(e[0], o[0]); v[3] = csub(e[0], o[0]);
+        v[1] = cadd(e[1], t1);   v[4] = csub(e[1], t1);
+        v[2] = cadd(e[2], t2);   v[5] = csub(e[2], t2);
+    } else if constexpr (R == 12) {
+        // 12 = 4 x 3, decimation in time over the three interleaved length-4 sequences x[3m + r]:
+        // F_r = DFT4; G_r[k1] = W12^(r k1) F_r[k1]; X[k1 + 4 k2] = DFT3 over r of G_r[k1]
+        double2 f0[4] = {v[0], v[3], v[6], v[9]}, f1[4] = {v[1], v[4], v[7], v[10]}, f2[4] = {v[2], v[5], v[8], v[11]};
+        small_dft<4, FWD>(f0);
+        small_dft<4, FWD>(f1);
+        small_dft<4, FWD>(f2);
+        const double c30 = 0.86602540378443864676, sg = FWD ? -1.0 : 1.0;
+        // W12^1 = (c30, sg/2), W12^2 = (1/2, sg c30), W12^3 = (0, sg), W12^4 = (-1/2, sg c30), W12^6 = -1
+        f1[1] = cmul(f1[1], make_double2(c30, sg * 0.5));
+        f1[2] = cmul(f1[2], make_double2(0.5, sg * c30));
+        f1[3] = FWD ? mul_mi(f1[3]) : mul_pi(f1[3]);
+        f2[1] = cmul(f2[1], make_double2(0.5, sg * c30));
+        f2[2] = cmul(f2[2], make_double2(-0.5, sg * c30));
+        f2[3] = make_double2(-f2[3].x, -f2[3].y);
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            double2 g[3] = {f0[k1], f1[k1], f2[k1]};
+            small_dft<3, FWD>(g);
+            v[k1] = g[0]; v[k1 + 4] = g[1]; v[k1 + 8] = g[2];
+        }
     } else {  // R == 3
         const double c = -0.5, s = 0.86602540378443864676;   // cos, sin of 2 pi / 3
         double2 t = cadd(v[1], v[2]);
@@ -120,6 +153,8 @@ template <bool FWD>
 __device__ __forceinline__ void fft_pass_any(int R, double2 *Z, int nl, int ls, int es, int n, int N,
                                              const double2 *__restrict__ tw) {
     if (R == 8) fft_pass<8, FWD>(Z, nl, ls, es, n, N, tw);
+    else if (R == 12) fft_pass<12, FWD>(Z, nl, ls, es, n, N, tw);
+    else if (R == 6) fft_pass<6, FWD>(Z, nl, ls, es, n, N, tw);
     else if (R == 4) fft_pass<4, FWD>(Z, nl, ls, es, n, N, tw);
     else if (R == 2) fft_pass<2, FWD>(Z, nl, ls, es, n, N, tw);
     else fft_pass<3, FWD>(Z, nl, ls, es, n, N, tw);
@@ -147,7 +182,11 @@ __device__ __forceinline__ void fft_lines_inv(double2 *Z, int nl, int ls, int es
 
 // ---- compile-time plans: the same greedy radix order as the host's factor_radices (8, 4, 2, 3), with
 // every size a constant so that the index arithmetic of the passes folds to shifts and multiplies
-constexpr int pick_radix(int n) { return n % 8 == 0 ? 8 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : 3)); }
+// (radix 12 = 4 x 3 and 6 = 2 x 3 finish 96 = 8 x 12 and 48 = 8 x 6 in two passes instead of three; the passes
+// are LDS-bandwidth bound, so a pass less is a third of the transform time less)
+constexpr int pick_radix(int n) {
+    return n % 8 == 0 ? 8 : (n % 12 == 0 ? 12 : ((n % 6 == 0 && n % 4 != 0) ? 6 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : 3))));
+}
 
 template <int N, int n>
 __device__ __forceinline__ void fft_lines_fwd_t(double2 *Z, int nl, int ls, int es, const double2 *tw) {

@@ -4,6 +4,7 @@
 // (constructed by the reference at pyqg_generative/tools/simulate.py:83,121 and
 // tools/stochastic_pyqg.py:78-88).
 #include "common.hpp"
+#include "fft_lds.hpp"
 #include <cmath>
 #include <new>
 
@@ -61,13 +62,16 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
 }
 
 static bool factor_radices(int N, int *rad, int &nrad) {
+    // the same greedy plan as the device's compile-time pick_radix (fft_lds.hpp)
     nrad = 0;
     int n = N;
-    while (n % 8 == 0) { rad[nrad++] = 8; n /= 8; }
-    while (n % 4 == 0) { rad[nrad++] = 4; n /= 4; }
-    while (n % 2 == 0) { rad[nrad++] = 2; n /= 2; }
-    while (n % 3 == 0) { rad[nrad++] = 3; n /= 3; }
-    return n == 1 && nrad <= MAX_RADIX_PASSES;
+    while (n > 1 && nrad < MAX_RADIX_PASSES) {
+        const int r = pick_radix(n);
+        if (n % r) return false;
+        rad[nrad++] = r;
+        n /= r;
+    }
+    return n == 1;
 }
 
 template <class T>
