@@ -144,7 +144,9 @@ enum qgx_diag {              /* per member; pyqg normalisation 1/M^2 */
     QGX_D_KEFLUX = 4,
     QGX_D_APEGENSPEC = 5,
     QGX_D_KEFRICTIONSPEC = 6,
-    QGX_D_PARAMSPEC = 7
+    QGX_D_PARAMSPEC = 7,
+    QGX_D_PARAMSPEC_APEFLUX = 8,   /* the APE and KE parts of paramspec (comparison_tools.py:174-176) */
+    QGX_D_PARAMSPEC_KEFLUX = 9
 };
 int qgx_diag_config(qgx_model *m, int64_t start_step, int every);   /* every <= 0 disables */
 int qgx_diag_get(qgx_model *m, int diag, double *out_dev, void *stream);   /* time mean */

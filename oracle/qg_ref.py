@@ -282,6 +282,14 @@ class QGModelRef:
         if self.q_parameterization is not None and hasattr(self, 'dqh'):
             d['paramspec'] = -np.real((self.Hi[:, None, None] / self.H
                                        * np.conj(self.ph) * self.dqh).sum(axis=0)) / M2
+            # the two parts of the energy budget the reference sums into its total flux
+            # (comparison_tools.py:174-176): with dph = a . dqh (the model's inversion of the
+            # parameterization's PV tendency), APE part + KE part == paramspec identically
+            dph = np.einsum('ij...,j...->i...', self.a, self.dqh)
+            d['paramspec_APEflux'] = self.rd ** -2 * self.del1 * self.del2 * np.real(
+                (self.ph[0] - self.ph[1]) * np.conj(dph[0] - dph[1])) / M2
+            d['paramspec_KEflux'] = self.wv2 * np.real(self.del1 * self.ph[0] * np.conj(dph[0])
+                                                       + self.del2 * self.ph[1] * np.conj(dph[1])) / M2
         return d
 
     def _advect_h(self, q, u, v):

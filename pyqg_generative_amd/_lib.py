@@ -41,7 +41,8 @@ class qgx_cnn_weights(C.Structure):
 F_Q, F_QH, F_PH, F_U, F_V, F_DQHDT, F_DQHDT_P, F_DQHDT_PP, F_S, F_Z = range(10)
 T_FILTR, T_WV2, T_A, T_KK, T_LL = range(5)
 SAMPLING_AR1, SAMPLING_CONSTANT = 0, 1
-DIAGS = ['KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec', 'paramspec']
+DIAGS = ['KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec', 'paramspec',
+         'paramspec_APEflux', 'paramspec_KEflux']
 GEN_GAN, GEN_VAE, GEN_GZ = 0, 1, 2
 
 # every symbol include/qgx.h declares: (name, restype, argtypes)

@@ -99,7 +99,7 @@ struct qgx_model {
     int dg_every = 0;
     double *dg_R[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double *dg_S[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    double *dg_acc[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *dg_acc[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace qgx {

@@ -2,8 +2,8 @@
 //
 // Restates pyqg 0.7.2 model.py::{_calc_diagnostics,_increment_diagnostics} and the diagnostic
 // definitions of model.py / qg_model.py (KEspec, Ensspec, entspec, APEflux, KEflux, APEgenspec,
-// KEfrictionspec, paramspec), which the reference consumes in
-// pyqg_generative/tools/comparison_tools.py:91,106,164-188,222-247 and plots as
+// KEfrictionspec, paramspec, paramspec_APEflux, paramspec_KEflux), which the reference consumes in
+// pyqg_generative/tools/comparison_tools.py:91,106,164-188 (paramspec_* at :174-176),222-247 and plots as
 // calc_ispec(m, 0.5*ave_lev(KEspec)) (Google-Colab/online-simulations.ipynb cell 25).
 // All spectra carry pyqg's 1/M^2 normalisation.  PARITY UNPINNED (pyqg is not available here):
 // checked against oracle/qg_ref.py::_diag_functions only.
@@ -46,7 +46,8 @@ __global__ void k_diag_products(SpecDev d, DiagConst c, const double *u, const d
     }
 }
 
-struct DiagAcc { double *KEspec, *Ensspec, *entspec, *APEflux, *KEflux, *APEgenspec, *KEfrictionspec, *paramspec; };
+struct DiagAcc { double *KEspec, *Ensspec, *entspec, *APEflux, *KEflux, *APEgenspec, *KEfrictionspec, *paramspec,
+                        *paramspec_APEflux, *paramspec_KEflux; };
 
 __global__ void k_diag_accumulate(SpecDev d, DiagConst c, const double2 *qh, const double2 *ph, const double2 *S3,
                                   const double2 *S4, const double2 *S5, const double2 *Sh, DiagAcc a) {
@@ -81,6 +82,15 @@ __global__ void k_diag_accumulate(SpecDev d, DiagConst c, const double2 *qh, con
             const double2 s1 = Sh[o], s2 = Sh[o + sz];
             // -Re[ sum_k Hk/H conj(ph_k) dqh_k ]
             a.paramspec[o2] += -(c.H0 * (p1.x * s1.x + p1.y * s1.y) + c.H1 * (p2.x * s2.x + p2.y * s2.y)) * c.invM2;
+            // its split into the available-potential and kinetic parts of the energy budget: with the streamfunction
+            // tendency of the parameterization dph = A dqh (the model's inversion),
+            //   paramspec_APEflux = rd^-2 del1 del2 Re[(p1 - p2) conj(dp1 - dp2)] / M^2
+            //   paramspec_KEflux  = wv2 sum_k del_k Re[p_k conj(dp_k)] / M^2,      APEflux + KEflux == paramspec
+            const double a00 = d.a[idx], a01 = d.a[sz + idx], a10 = d.a[2 * sz + idx], a11 = d.a[3 * sz + idx];
+            const double d1x = a00 * s1.x + a01 * s2.x, d1y = a00 * s1.y + a01 * s2.y;
+            const double d2x = a10 * s1.x + a11 * s2.x, d2y = a10 * s1.y + a11 * s2.y;
+            a.paramspec_APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * (d1x - d2x) + dpy * (d1y - d2y)) * c.invM2;
+            a.paramspec_KEflux[o2] += wv2 * (c.del1 * (p1.x * d1x + p1.y * d1y) + c.del2 * (p2.x * d2x + p2.y * d2y)) * c.invM2;
         }
     }
 }
@@ -110,7 +120,7 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
         for (int i = 0; i < 5; ++i) if ((rc = dalloc0(m->dg_R[i], nr))) return rc;
         for (int i = 0; i < 5; ++i) if ((rc = dalloc0(m->dg_S[i], ns2))) return rc;
         for (int i = 0; i < 2; ++i) if ((rc = dalloc0(m->dg_acc[i], ns2 / 2))) return rc;
-        for (int i = 2; i < 8; ++i) if ((rc = dalloc0(m->dg_acc[i], n2d))) return rc;
+        for (int i = 2; i < 10; ++i) if ((rc = dalloc0(m->dg_acc[i], n2d))) return rc;
     }
     double2 *qh = m->qh[m->cur_q];
     double *p = m->dg_R[0], *xi = m->dg_R[1], *R3 = m->dg_R[2], *R4 = m->dg_R[3], *R5 = m->dg_R[4];
@@ -139,6 +149,7 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
     DiagAcc a;
     a.KEspec = m->dg_acc[0]; a.Ensspec = m->dg_acc[1]; a.entspec = m->dg_acc[2]; a.APEflux = m->dg_acc[3];
     a.KEflux = m->dg_acc[4]; a.APEgenspec = m->dg_acc[5]; a.KEfrictionspec = m->dg_acc[6]; a.paramspec = m->dg_acc[7];
+    a.paramspec_APEflux = m->dg_acc[8]; a.paramspec_KEflux = m->dg_acc[9];
     hipLaunchKernelGGL(k_diag_accumulate, dgrid(d, d.N * d.NK), dim3(256), 0, st, d, c, (const double2 *)qh,
                        (const double2 *)m->ph, (const double2 *)S3, (const double2 *)S4, (const double2 *)S5, Shp, a);
     QGX_HIP(hipGetLastError());
@@ -164,13 +175,13 @@ extern "C" int qgx_diag_reset(qgx_model *m) {
     m->dg_count = 0;
     if (m->dg_acc[0]) {
         const size_t ns = (size_t)m->B * 2 * m->N * m->NK, n2 = (size_t)m->B * m->N * m->NK;
-        for (int i = 0; i < 8; ++i) QGX_HIP(hipMemset(m->dg_acc[i], 0, (i < 2 ? ns : n2) * sizeof(double)));
+        for (int i = 0; i < 10; ++i) QGX_HIP(hipMemset(m->dg_acc[i], 0, (i < 2 ? ns : n2) * sizeof(double)));
     }
     return QGX_OK;
 }
 
 extern "C" int qgx_diag_get(qgx_model *m, int diag, double *out_dev, void *stream) {
-    QGX_REQUIRE(m && out_dev && diag >= 0 && diag < 8, "qgx_diag_get: bad argument");
+    QGX_REQUIRE(m && out_dev && diag >= 0 && diag < 10, "qgx_diag_get: bad argument");
     QGX_REQUIRE(m->dg_count > 0 && m->dg_acc[0], "qgx_diag_get: no diagnostics accumulated yet");
     const size_t n = (size_t)m->B * (diag < 2 ? 2 : 1) * m->N * m->NK;
     hipLaunchKernelGGL(k_diag_scale_copy, dim3(1024), dim3(256), 0, (hipStream_t)stream,

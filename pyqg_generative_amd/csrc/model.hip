@@ -250,7 +250,7 @@ extern "C" int qgx_destroy(qgx_model *m) {
                     m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->zbuf,
                     m->z, m->xi, m->dg_R[0], m->dg_R[1], m->dg_R[2], m->dg_R[3], m->dg_R[4], m->dg_S[0], m->dg_S[1],
                     m->dg_S[2], m->dg_S[3], m->dg_S[4], m->dg_acc[0], m->dg_acc[1], m->dg_acc[2], m->dg_acc[3],
-                    m->dg_acc[4], m->dg_acc[5], m->dg_acc[6], m->dg_acc[7]};
+                    m->dg_acc[4], m->dg_acc[5], m->dg_acc[6], m->dg_acc[7], m->dg_acc[8], m->dg_acc[9]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete m;
     return QGX_OK;

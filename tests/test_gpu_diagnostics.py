@@ -66,6 +66,14 @@ def test_paramspec_and_dataset_export():
     r.run()
     got, ref = m.get_diagnostic('paramspec'), r.get_diagnostic('paramspec')
     assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+    # its available-potential / kinetic split (summed by the reference's total energy flux,
+    # comparison_tools.py:174-176): against the oracle, and the budget identity APE + KE == total
+    parts = 0.0
+    for name in ('paramspec_APEflux', 'paramspec_KEflux'):
+        g, rr = m.get_diagnostic(name), r.get_diagnostic(name)
+        assert np.abs(g - rr).max() <= 1e-9 * np.abs(rr).max(), name
+        parts = parts + g
+    assert np.abs(parts - got).max() <= 1e-10 * np.abs(got).max()
     ds = snapshot_dataset(m)
     assert ds['KEspec'].shape == (2, N, N // 2 + 1) and ds['KEflux'].shape == (N, N // 2 + 1)
     assert ds['q'].shape == (1, 2, N, N)
