@@ -41,3 +41,6 @@ if os.environ.get('QGX_STAMPS_REALTIME'):
     en = (last - t0) * 0.01
     print(f'start after the first workgroup (us): median {np.median(st):.1f} p90 {np.percentile(st, 90):.1f} max {st.max():.1f}')
     print(f'end after the first start (us): min {en.min():.1f} median {np.median(en):.1f} max {en.max():.1f}; lifetime median {np.median(en - st):.1f}')
+    print('mean end by workgroup index mod 8 (XCD):', ' '.join(f'{en[x::8].mean():.1f}' for x in range(8)))
+    print('mean end by index quarter:', ' '.join(f'{q.mean():.1f}' for q in np.array_split(en, 4)))
+    print('spread within XCD 0 (min/median/max):', f'{en[0::8].min():.1f} {np.median(en[0::8]):.1f} {en[0::8].max():.1f}')

@@ -762,6 +762,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_prio_alt = 1;          // k_convh2 with two workgroups per CU: alternate their wave priority per tile
     int opt_h4 = 0;                // 5x5 layer: k_convh4 (full-line patch chunks, 8 waves, R = 8)
     int opt_h2_grid = 0;           // k_convh2: persistent workgroups per launch (0 = one or two per CU by LDS size)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
@@ -1297,6 +1298,7 @@ static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, cons
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
     a.N = NN; a.R = R;
+    a.prio_alt = KS == 5 ? g->opt_prio_alt : 0;      // measured: -2 % on the 5x5 layer, nothing on the 3x3 layers
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (NN / R);
     int grid = lds * 2 <= 160 * 1024 ? 512 : 256;
@@ -1819,6 +1821,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "fold")) g->opt_fold = value ? 1 : 0;
     else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
     else if (!strcmp(name, "h4")) g->opt_h4 = value;
+    else if (!strcmp(name, "prio_alt")) g->opt_prio_alt = value;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }

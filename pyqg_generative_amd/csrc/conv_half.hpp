@@ -42,6 +42,7 @@ struct ConvHArgs {
     float ascale;          // pre-scale of the stored output activations, a power of two
     int N, R;
     size_t npix_total;     // split-K: B*N*N, the stride of one partial-sum plane
+    int prio_alt;          // k_convh2: alternate the wave priority of the two co-resident workgroups per tile
     unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only: s_memtime trace, 64 slots per workgroup
 };
 
@@ -52,7 +53,10 @@ struct ConvHArgs {
 #define QGX_STAMP_CLOCK __builtin_amdgcn_s_memtime
 #endif
 #define QGX_STAMP()                                                                          \
-    if (a.stamps && threadIdx.x == 0 && stamp_i < 64) a.stamps[blockIdx.x * 64 + stamp_i++] = QGX_STAMP_CLOCK();
+    if (a.stamps && threadIdx.x == 0) {                                                      \
+        a.stamps[blockIdx.x * 64 + (stamp_i < 63 ? stamp_i : 63)] = QGX_STAMP_CLOCK();       \
+        if (stamp_i < 63) ++stamp_i;                                                         \
+    }
 #else
 #define QGX_STAMP()
 #endif
@@ -507,6 +511,13 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
     f32x16 acc[MT][NT];
     int cur_w = 0;
     for (int ti = 0; ti < n_my; ++ti) {
+        // two workgroups share a CU and the older one wins every issue arbitration: it finished its tiles 12-19 %
+        // earlier and left the younger one to run alone (without a partner to hide its latencies) at the end.
+        // Alternating the wave priority per tile between the two keeps them in step.
+        if (TWO && a.prio_alt == 1) {
+            if ((ti ^ (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // PAIR: a run-time loop over chunk pairs with the two chunks of a pair unrolled (the parity decides
         // which prefetch set is loaded / stored, so it has to be a compile-time constant)
         for (int cp = cbeg; cp < cend; cp += (PAIR ? 2 : 1))
@@ -514,6 +525,10 @@ __global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int to
         for (int ci = 0; ci < (PAIR ? 2 : 1); ++ci) {
             const int ch = cp + ci;
             const bool odd = ci == 1;
+            if (TWO && a.prio_alt == 2) {
+                if ((ch ^ ti ^ (blockIdx.x >= (gridDim.x >> 1) ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             if (ch == cbeg) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
