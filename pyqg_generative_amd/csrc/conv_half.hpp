@@ -380,9 +380,10 @@ __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles)
 // KS/2 columns on both sides, so a tap is a compile-time byte offset from ONE per-lane base address
 // (ds_read offset immediates, no address arithmetic, no address registers).  The weight slice is single
 // buffered where two buffers would not leave room for two workgroups (the 5x5 layer).
-template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB, bool TWO, bool PAIR = false, bool PART = false>
-__global__ __launch_bounds__(256, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int total_tiles) {
-    constexpr int NW = 4, NTHR = 256;
+template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB, bool TWO, bool PAIR = false, bool PART = false,
+          int NW = 4>
+__global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int total_tiles) {
+    constexpr int NTHR = NW * 64;
     constexpr int NT = COUT / 32;
     constexpr int P = KS / 2, T = KS * KS;
     constexpr int NCH = CIN / 16;
