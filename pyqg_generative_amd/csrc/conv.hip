@@ -762,7 +762,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
-    int opt_h2_w8 = 1;             // 5x5 layer: k_convh2 as one 8-wave workgroup per CU
+    int opt_h2_w8 = 3;             // k_convh2 as one 8-wave workgroup per CU: bit 0 the 5x5 layer, bit 1 the 3x3 layers (64 x 64)
     int opt_prio_alt = 1;          // k_convh2 with two workgroups per CU: alternate their wave priority per tile
     int opt_h4 = 0;                // 5x5 layer: k_convh4 (full-line patch chunks, 8 waves, R = 8)
     int opt_h2_grid = 0;           // k_convh2: persistent workgroups per launch (0 = one or two per CU by LDS size)
@@ -1391,10 +1391,36 @@ static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, con
     return QGX_OK;
 }
 
+// the 3x3 layers in the same 8-wave shape (64 x 64)
+template <int CIN, bool OUTF32>
+static int launch_convh2_w8_3x3(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, hipStream_t st) {
+    constexpr int COUT = 32, KS = 3, NN = 64, MT = 2, TPS = 9, NW = 8;
+    constexpr int R = NW * MT * 32 / NN, PR = R + KS - 1, PW = NN + 2;
+    constexpr size_t lds = (size_t)PR * PW * 80 + (size_t)2 * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    ConvHArgs a = {};
+    a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.N = NN; a.R = R;
+    const int total_tiles = B * (NN / R);
+    int grid = 256;
+    if (grid > total_tiles) grid = total_tiles;
+    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, true, false, true, false, NW>;
+    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    return QGX_OK;
+}
+
 template <int CIN, int COUT, int KS, bool OUTF32>
 static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
                          hipStream_t st, bool &done) {
     done = true;
+    if constexpr (KS == 3 && COUT == 32) {
+        if ((g->opt_h2_w8 & 2) && g->opt_pair && N == 64 && B * 8 >= 256) return launch_convh2_w8_3x3<CIN, OUTF32>(g, layer, L, in, out, B, st);
+    }
     if constexpr (KS == 5 && CIN == 128) {
         // one 8-wave workgroup per CU once its double-height tiles fill the CUs: -5.5 % at 64 x 64, -3.5 % at
         // 32 x 32; the three-tile-per-wave shapes of 96 / 48 spill at 256 registers (+40 %), 128 ties
@@ -1856,7 +1882,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
     else if (!strcmp(name, "h4")) g->opt_h4 = value;
     else if (!strcmp(name, "prio_alt")) g->opt_prio_alt = value;
-    else if (!strcmp(name, "h2_w8")) g->opt_h2_w8 = value ? 1 : 0;
+    else if (!strcmp(name, "h2_w8")) g->opt_h2_w8 = value & 3;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }

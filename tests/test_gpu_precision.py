@@ -102,7 +102,7 @@ VARIANTS = [
     dict(h2=3, fuse=2),
     dict(h3=1),                                  # 5x5 layer on 16x16x32 MFMAs (k_convh3)
     dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
-    dict(h2_w8=0),                               # 5x5 layer as two 4-wave workgroups per CU instead of one 8-wave
+    dict(h2_w8=0), dict(h2_w8=1),                # 4-wave x 2 workgroups per CU instead of one 8-wave workgroup
     dict(first_h=0),                             # exact-f32 first layer writing the 16-bit layout
     dict(fold=0),                                # layer 1's BatchNorm applied in its epilogue instead of folded into layer 2
     dict(member_chunk=16),                       # member sub-batches
@@ -120,7 +120,7 @@ def test_optional_kernel_variants_agree(N, B):
     ref = gen.cnn_forward(x).cpu().numpy()
     gen.set_option('precision', 3)
     gen.set_option('part_max_tiles', 0)
-    defaults = dict(h2=3, half_nw=8, res=1, fuse=3, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h4=0, h2_w8=1)
+    defaults = dict(h2=3, half_nw=8, res=1, fuse=3, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h4=0, h2_w8=3)
     for v in VARIANTS:
         for k, d in defaults.items():
             gen.set_option(k, v.get(k, d))
