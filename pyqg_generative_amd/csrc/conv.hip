@@ -762,6 +762,7 @@ struct qgx_generator {
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
+    int opt_h2_tw32 = 0;           // 5x5 layer at 64 x 64: 16-row x 32-column tiles instead of 8 full rows
     int opt_h2_w8 = 3;             // k_convh2 as one 8-wave workgroup per CU: bit 0 the 5x5 layer, bit 1 the 3x3 layers (64 x 64)
     int opt_prio_alt = 1;          // k_convh2 with two workgroups per CU: alternate their wave priority per tile
     int opt_h4 = 0;                // 5x5 layer: k_convh4 (full-line patch chunks, 8 waves, R = 8)
@@ -1368,10 +1369,10 @@ static int launch_convh2_part(qgx_generator *g, int layer, const LayerHost &L, c
 
 // the 5x5 layer as ONE 8-wave workgroup per CU (R = 8 rows at 64 x 64: row halo 1.5x instead of 2x, half the
 // weight traffic, double-buffered weight slice, 7 + 3 prefetch registers per thread)
-template <int NN, int MT>
+template <int NN, int MT, int TW = NN>
 static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, hipStream_t st) {
     constexpr int CIN = 128, COUT = 64, KS = 5, TPS = 5, NW = 8;
-    constexpr int R = NW * MT * 32 / NN, PR = R + KS - 1, PW = NN + 4;
+    constexpr int R = NW * MT * 32 / TW, PR = R + KS - 1, PW = TW + 4;
     constexpr size_t lds = (size_t)PR * PW * 80 + (size_t)2 * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
     hipEvent_t prof_stop;
@@ -1380,10 +1381,10 @@ static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, con
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
     a.N = NN; a.R = R;
-    const int total_tiles = B * (NN / R);
+    const int total_tiles = B * (NN / R) * (NN / TW);
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
-    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, false, true, false, false, false, NW>;
+    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, false, true, false, false, false, NW, TW>;
     QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
@@ -1425,8 +1426,11 @@ static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const 
         // one 8-wave workgroup per CU once its double-height tiles fill the CUs: -5.5 % at 64 x 64, -3.5 % at
         // 32 x 32; the three-tile-per-wave shapes of 96 / 48 spill at 256 registers (+40 %), 128 ties
         if (g->opt_h2_w8) {
-            if (N == 64 && B * 8 >= 256) return launch_convh2_w8<64, 2>(g, layer, L, in, out, B, st);
+            if (N == 64 && B * 8 >= 256)
+                return g->opt_h2_tw32 ? launch_convh2_w8<64, 2, 32>(g, layer, L, in, out, B, st) : launch_convh2_w8<64, 2>(g, layer, L, in, out, B, st);
             if (N == 32 && B * 2 >= 256) return launch_convh2_w8<32, 2>(g, layer, L, in, out, B, st);
+            // 96 = 3 x 32: tiles of 16 rows x 32 columns keep the two-M-tiles-per-wave shape
+            if (N == 96 && B * 18 >= 1024) return launch_convh2_w8<96, 2, 32>(g, layer, L, in, out, B, st);
         }
     }
     switch (N) {
@@ -1883,6 +1887,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "h4")) g->opt_h4 = value;
     else if (!strcmp(name, "prio_alt")) g->opt_prio_alt = value;
     else if (!strcmp(name, "h2_w8")) g->opt_h2_w8 = value & 3;
+    else if (!strcmp(name, "h2_tw32")) g->opt_h2_tw32 = value ? 1 : 0;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }

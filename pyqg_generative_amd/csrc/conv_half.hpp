@@ -380,21 +380,24 @@ __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles)
 // KS/2 columns on both sides, so a tap is a compile-time byte offset from ONE per-lane base address
 // (ds_read offset immediates, no address arithmetic, no address registers).  The weight slice is single
 // buffered where two buffers would not leave room for two workgroups (the 5x5 layer).
+// TW: tile width (default: full rows).  TW < NN tiles the image in x as well (96 = 3 x 32: sixteen 32-pixel rows
+// give the two-M-tiles-per-wave shape that does not spill, where full 96-pixel rows need three).
 template <int CIN, int COUT, int KS, int NN, int MT, int TPS, bool OUTF32, bool WDB, bool TWO, bool PAIR = false, bool PART = false,
-          int NW = 4>
+          int NW = 4, int TW = NN>
 __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, int total_tiles) {
     constexpr int NTHR = NW * 64;
     constexpr int NT = COUT / 32;
     constexpr int P = KS / 2, T = KS * KS;
     constexpr int NCH = CIN / 16;
     constexpr int PIXB = CIN * 4, OPIXB = COUT * 4;
-    constexpr int N = NN, R = NW * MT * 32 / NN, PR = R + KS - 1, PW = NN + 2 * P;
+    constexpr int N = NN, R = NW * MT * 32 / TW, PR = R + KS - 1, PW = TW + 2 * P, XT = NN / TW;
     constexpr int PSTR = 80;
     constexpr int patch_bytes = PR * PW * PSTR;
     constexpr int TAPB = 4 * COUT * 16, WSB = TPS * TAPB, NSL = T / TPS;
     constexpr int PU = PR * PW * 4, PPT = (PU + NTHR - 1) / NTHR;
     constexpr int WU = WSB / 16, WPT = (WU + NTHR - 1) / NTHR;
-    static_assert(T % TPS == 0 && (NW * MT * 32) % NN == 0 && NN % R == 0, "shape");
+    static_assert(T % TPS == 0 && (NW * MT * 32) % TW == 0 && NN % R == 0 && NN % TW == 0 && (TW == NN || TW % 32 == 0), "shape");
+    static_assert(TW == NN || !PART, "split-K uses full-row tiles");
     static_assert(!PAIR || (NCH % 2 == 0 && NSL == 1), "line-pair prefetch: even chunk count, one slice per chunk");
     static_assert(!(PAIR && PART), "split-K runs without the line-pair prefetch");
     // PART (single members): blockIdx.y owns the chunks [cbeg, cend) of every tile and stores raw f32 partial
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
     float *const ep = reinterpret_cast<float *>(wlds0 + (WDB ? 2 : 1) * WSB);
     const char *const inb = reinterpret_cast<const char *>(a.in);
     const char *const wb = reinterpret_cast<const char *>(a.w);
-    constexpr int tiles_per_img = N / R;
+    constexpr int tiles_per_img = (N / R) * XT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -419,13 +422,14 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
     {                                                                                                       \
         const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
         const int b_ = tile_ / tiles_per_img;                                                               \
-        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        const int tr_ = tile_ - b_ * tiles_per_img;                                                         \
+        const int y0_ = (tr_ / XT) * R, x0_ = (tr_ % XT) * TW;                                              \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
             int it_ = u * NTHR + threadIdx.x;                                                                \
             it_ = it_ < PU ? it_ : PU - 1;                                                                  \
             const int un_ = it_ & 3, pl_ = it_ >> 2;                                                        \
             const int pr_ = pl_ / PW, xx_ = pl_ - pr_ * PW;                                                 \
-            int gy_ = y0_ - P + pr_, gx_ = xx_ - P;                                                         \
+            int gy_ = y0_ - P + pr_, gx_ = x0_ + xx_ - P;                                                   \
             gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                           \
             gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                           \
             V[u] = *reinterpret_cast<const f32x4 *>(                                                        \
@@ -436,12 +440,13 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
     {                                                                                                       \
         const int tile_ = blockIdx.x + (TI) * gridDim.x;                                                    \
         const int b_ = tile_ / tiles_per_img;                                                               \
-        const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
+        const int tr_ = tile_ - b_ * tiles_per_img;                                                         \
+        const int y0_ = (tr_ / XT) * R, x0_ = (tr_ % XT) * TW;                                              \
         int it_ = (U) * NTHR + threadIdx.x;                                                                  \
         it_ = it_ < PU ? it_ : PU - 1;                                                                      \
         const int un_ = it_ & 3, pl_ = it_ >> 2;                                                            \
         const int pr_ = pl_ / PW, xx_ = pl_ - pr_ * PW;                                                     \
-        int gy_ = y0_ - P + pr_, gx_ = xx_ - P;                                                             \
+        int gy_ = y0_ - P + pr_, gx_ = x0_ + xx_ - P;                                                       \
         gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                               \
         gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                               \
         V[U] = *reinterpret_cast<const f32x4 *>(                                                            \
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int p = (wave + NW * mt) * 32 + li;
-        const int py = p / NN, px = p - py * NN;
+        const int py = p / TW, px = p - py * TW;
         pbase[mt] = (py * PW + px) * PSTR + h * 32;
     }
     const int wofs = (h * COUT + li) * 16;
@@ -643,7 +648,8 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
                 if (sl == NSL - 1 && ch == cend - 1) {
                     const int tile_g = blockIdx.x + ti * gridDim.x;
                     const int b = tile_g / tiles_per_img;
-                    const int y0 = (tile_g - b * tiles_per_img) * R;
+                    const int tr = tile_g - b * tiles_per_img;
+                    const int y0 = (tr / XT) * R, x0 = (tr % XT) * TW;
                     if constexpr (PART) {
                         // raw partial sums, f32 [split][pixel][cout]: register quad q of a lane = 4 consecutive channels
                         float *pb = reinterpret_cast<float *>(a.out) +
@@ -658,10 +664,11 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
                                     *reinterpret_cast<f32x4 *>(pb + (size_t)((wave + NW * mt) * 32 + li) * COUT + nt * 32 + 8 * q4 + 4 * h) = v;
                                 }
                     } else {
-                        char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N) * OPIXB;
+                        char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N + x0) * OPIXB;
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            char *pix = ob + (size_t)((wave + NW * mt) * 32 + li) * OPIXB;
+                            const int p = (wave + NW * mt) * 32 + li;
+                            char *pix = ob + (size_t)((p / TW) * N + p % TW) * OPIXB;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
                                 store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
