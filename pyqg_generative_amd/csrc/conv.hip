@@ -1584,31 +1584,39 @@ static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, 
 template <int NIN>
 static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float *in, void *out, int B, int N,
                               hipStream_t st) {
-    const int R = choose_rows(N);
+    int R = choose_rows(N);
     QGX_REQUIRE(R > 0 && N % R == 0 && N % 4 == 0, "generator: unsupported grid size N=%d", N);
+    // one 8-wave workgroup per CU with double-height tiles where two M-tiles per wave result (64 x 64, 32 x 32) and
+    // the ensemble fills the CUs: of two co-resident 4-wave workgroups the older wins every issue arbitration and
+    // the younger finishes 30 % later (global-clock stamps), and the 57 KB weight set is staged once per CU
+    const bool w8 = g->opt_h2_w8 && R * N / 32 == 8 && N % (2 * R) == 0 && B * (N / (2 * R)) >= 256;
+    if (w8) R *= 2;
+    const int nw = w8 ? 8 : 4;
     const int PR = R + 4, ntiles = R * N / 32;
     constexpr int nstep = NIN == 4 ? 7 : 4;
     const size_t lds = (size_t)nstep * 4 * 128 * 16 + (size_t)2 * PR * N * NIN * 4 + 3 * 128 * sizeof(float);
-    const int ppt = (PR * NIN * (N / 4) + 255) / 256;
-    QGX_REQUIRE(lds <= 160 * 1024 - 256 && ppt <= 3 && (ntiles == 8 || ntiles == 12),
+    const int ppt = (PR * NIN * (N / 4) + nw * 64 - 1) / (nw * 64);
+    QGX_REQUIRE(lds <= 160 * 1024 - 256 && ppt <= 3 && (ntiles == 2 * nw || ntiles == 3 * nw),
                 "generator: 16-bit first layer unsupported for N=%d", N);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, 0, st, prof_stop); if (prc) return prc; }
-    ConvHFirstArgs a;
+    ConvHFirstArgs a = {};
+    a.stamps = g->stamp_layer == 0 ? g->stamps : nullptr;
     a.in = in; a.out = out; a.w = L.whf; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.whf_unscale; a.ascale = g->opt_ascale; a.N = N; a.R = R;
     const int total_tiles = B * (N / R);
     const int wgs = lds * 2 <= 160 * 1024 ? 2 : 1;
     int grid = 256 * wgs;
     if (grid > total_tiles) grid = total_tiles;
-#define QGX_LF(MTV, PPTV)                                                                                     \
+#define QGX_LF(MTV, PPTV, NWV)                                                                                \
     {                                                                                                         \
-        auto kern = k_convh_first<NIN, MTV, PPTV>;                                                            \
+        auto kern = k_convh_first<NIN, MTV, PPTV, NWV>;                                                       \
         QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);                             \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, a, total_tiles);                        \
     }
-    if (ntiles == 8) { if (ppt <= 2) QGX_LF(2, 2) else QGX_LF(2, 3) }
-    else { if (ppt <= 2) QGX_LF(3, 2) else QGX_LF(3, 3) }
+    if (w8) { if (ppt <= 2) QGX_LF(2, 2, 8) else QGX_LF(2, 3, 8) }
+    else if (ntiles == 8) { if (ppt <= 2) QGX_LF(2, 2, 4) else QGX_LF(2, 3, 4) }
+    else { if (ppt <= 2) QGX_LF(3, 2, 4) else QGX_LF(3, 3, 4) }
 #undef QGX_LF
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));

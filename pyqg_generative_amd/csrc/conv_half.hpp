@@ -744,10 +744,12 @@ struct ConvHFirstArgs {
     const float *bias, *scale, *shift;
     float unscale, ascale;
     int N, R;
+    unsigned long long *stamps;   // diagnostic builds only
 };
 
-template <int NIN, int MT, int PPT>
-__global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total_tiles) {
+template <int NIN, int MT, int PPT, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int total_tiles) {
+    constexpr int NTHR = NW * 64;
     constexpr int KS = 5, P = 2, T = 25, COUT = 128;
     constexpr int TPF = 8 / NIN;                 // taps per 8-element fragment
     constexpr int TPS = 2 * TPF;                 // taps per K = 16 step
@@ -768,6 +770,9 @@ __global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total
     const int NX4 = N / 4;
     const int PI = PR * NIN * NX4;               // float4 items of one patch
     if (n_my == 0) return;
+    int stamp_i = 0;
+    (void)stamp_i;
+    QGX_STAMP()
 
 #define QGX_F_LOAD(TI, V)                                                                                   \
     {                                                                                                       \
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total
         const int b_ = tile_ / tiles_per_img;                                                               \
         const int y0_ = (tile_ - b_ * tiles_per_img) * R;                                                   \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
-            int it_ = u * 256 + threadIdx.x;                                                                 \
+            int it_ = u * NTHR + threadIdx.x;                                                                 \
             it_ = it_ < PI ? it_ : PI - 1;                                                                  \
             const int x4_ = it_ % NX4, c_ = (it_ / NX4) % NIN, pr_ = it_ / (NX4 * NIN);                     \
             int gy_ = y0_ - P + pr_;                                                                        \
@@ -786,7 +791,7 @@ __global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total
 #define QGX_F_STORE(BUF, V)                                                                                 \
     {                                                                                                       \
         _Pragma("unroll") for (int u = 0; u < PPT; ++u) {                                                   \
-            const int it_ = u * 256 + threadIdx.x;                                                           \
+            const int it_ = u * NTHR + threadIdx.x;                                                           \
             if (it_ < PI) {                                                                                 \
                 const int x4_ = it_ % NX4, c_ = (it_ / NX4) % NIN, pr_ = it_ / (NX4 * NIN);                 \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                             \
@@ -800,28 +805,29 @@ __global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total
         }                                                                                                   \
     }
 
-    for (int i = threadIdx.x; i < 3 * COUT; i += 256)
+    for (int i = threadIdx.x; i < 3 * COUT; i += NTHR)
         ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : a.shift[i - 2 * COUT]);
     // ---- prologue: weights (once) and the first patch
     {
-        f32x4 pv[PPT], wtmp[(WBYTES / 16 + 255) / 256];
+        f32x4 pv[PPT], wtmp[(WBYTES / 16 + NTHR - 1) / NTHR];
         QGX_F_LOAD(0, pv)
-        QGX_BULK_LOAD(wtmp, a.w, WBYTES / 16, 256)
+        QGX_BULK_LOAD(wtmp, a.w, WBYTES / 16, NTHR)
         QGX_F_STORE(pl0, pv)
-        QGX_BULK_STORE(wtmp, wl0, WBYTES / 16, 256)
+        QGX_BULK_STORE(wtmp, wl0, WBYTES / 16, NTHR)
     }
     __syncthreads();
 
     int py[MT], px[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int tile = wave + 4 * mt;
+        int tile = wave + NW * mt;
         if (tile >= ntiles) tile = wave % ntiles;
         const int p = tile * 32 + li;
         py[mt] = p / N;
         px[mt] = p - py[mt] * N;
     }
     int cur = 0;
+    QGX_STAMP()
     for (int ti = 0; ti < n_my; ++ti) {
         const bool have_next = ti + 1 < n_my;
         f32x4 pv[PPT];
@@ -882,20 +888,23 @@ __global__ __launch_bounds__(256) void k_convh_first(ConvHFirstArgs a, int total
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Ph[mt], acc[mt][nt], 0, 0, 0);
                     }
             }
+            QGX_STAMP()
             // the next patch goes to LDS before this tile's first output store is issued: waiting for its
             // loads later would also wait for those stores (one in-order counter)
             if (half == 0 && have_next) QGX_F_STORE(pl0 + (cur ^ 1) * patch_bytes, pv)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int tile = wave + 4 * mt;
+                const int tile = wave + NW * mt;
                 if (tile >= ntiles) continue;
                 char *pix = ob + (size_t)(tile * 32 + li) * (COUT * 4);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     store_tile_t<2, false>(acc[mt][nt], half * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
             }
+            QGX_STAMP()
         }
         __syncthreads();
+        QGX_STAMP()
         cur ^= 1;
     }
 #undef QGX_F_LOAD
