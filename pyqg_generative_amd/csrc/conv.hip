@@ -1381,6 +1381,7 @@ static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, con
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
     a.N = NN; a.R = R;
+    a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (NN / R) * (NN / TW);
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
@@ -1404,6 +1405,7 @@ static int launch_convh2_w8_3x3(qgx_generator *g, int layer, const LayerHost &L,
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
     a.N = NN; a.R = R;
+    a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (NN / R);
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
