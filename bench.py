@@ -1,20 +1,29 @@
 #!/usr/bin/env python
 """Headline benchmark: ensemble-timesteps/sec of the online parameterized-QG loop
-(64x64 two-layer eddy configuration + CGAN subgrid parameterization).
+(64x64 two-layer eddy configuration + CGAN subgrid parameterization; BASELINE.json `metric`).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" advances every resident ensemble member by one model time step:
-latent-noise draw (Philox), generator forward (8 conv layers, f32 MFMA), per-layer
-de-mean, and the pseudo-spectral step (6 packed complex FFTs, inversion, advection,
-friction, AB3 + exponential filter), all in float64 except the generator (float32,
-the reference's own precision).  Members are sharded over ranks with no data-path
-collective (weak scaling: --members per GPU is fixed; 128/GPU = BASELINE configs[2]'s
+One "step" advances every resident ensemble member by one model time step: latent-noise draw
+(Philox), generator forward (8 conv layers on the matrix cores), per-layer de-mean, and the
+pseudo-spectral step (packed complex FFTs, inversion, advection, friction, AB3 + exponential
+filter) in float64.  The timed region is the reference's loop (tools/simulate.py:137-139) at the
+reference's cadences: time-averaged spectral diagnostics every ceil(86400/dt) steps,
+a snapshot (q, u, v, psi -> float32 on the host) every ceil(3.6e6/dt) steps, the KE/CFL status
+check every 1000 steps, and — at snapshot time — the ensemble-mean KE spectrum (the ONE collective
+of the path: an all-reduce of per-rank partial sums).  Members are sharded over ranks with no
+data-path collective (weak scaling: --members per GPU is fixed; 128/GPU = BASELINE configs[2]'s
 1024 members on 8 GPUs).  Rank 0 prints ONE JSON line.
+
+Auxiliary legs on one GPU (same JSON line): `exact_f32` (the same workload on the f32 matrix cores),
+`b1` (configs[1]: one member), `config3` (96x96 jet + CVAE, 32 members = configs[3]'s per-GPU shard),
+`config4` (256x256 unparameterized, 64 members, with a coarse-grain + subgrid-forcing diagnostic to
+64x64 per snapshot = configs[4]), `cpu_baseline` (the CPU oracle on this box's host cores).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -26,9 +35,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MAC_PER_PIXEL = [12800, 204800, 18432, 9216, 9216, 9216, 9216, 576]   # SURVEY §8(d), GAN/VAE nets
-F32_MFMA_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md
+F32_MFMA_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md, dense f32 matrix
 F16_MFMA_PEAK_TFLOPS = 2500.0                                          # dense f16/bf16, same guide
+HBM_PEAK_GBS = 8000.0                                                  # HBM3E, same guide
 PRECISIONS = {'f32': 0, 'f16x3': 3, 'f16': 1}
+JET = dict(rek=7e-8, delta=0.1, beta=1e-11)                            # tools/parameters.py:26-27,37
+
+
+def dt_of(N):
+    return 14400. if N <= 64 else (7200. if N <= 128 else 3600.)      # tools/parameters.py:12-31
 
 
 def eddy_like_q(member_ids, N):
@@ -58,6 +73,97 @@ def load_generator(kind, device):
     return qa.Generator(kind, nets, xs, ys, device=device), src
 
 
+class OnlineLoop:
+    """The reference's run loop around qgx_step: chunks of steps between cadence boundaries."""
+
+    def __init__(self, eng, dt, step_kw, dist=None, backend='nccl'):
+        from pyqg_generative_amd import _lib
+        self.L = _lib
+        self.eng, self.step_kw, self.dist, self.backend = eng, step_kw, dist, backend
+        self.snap_every = int(math.ceil(3.6e6 / dt))          # ANDREW_1000_STEPS (parameters.py:9)
+        self.status_every = 1000                               # pyqg twrite
+        eng.diag_config(0, int(math.ceil(86400. / dt)))       # pyqg taveint (averaging phase of a run)
+        B, N = eng.B, eng.N
+        self.host = torch.empty((4, B, 2, N, N), dtype=torch.float32).pin_memory()
+        self.nsnap = self.nstatus = 0
+        self.mean_spec = None
+
+    def snapshot(self):
+        e, L = self.eng, self.L
+        for i, f in enumerate((L.F_Q, L.F_U, L.F_V, L.F_P)):
+            self.host[i].copy_(e.get(f).to(torch.float32), non_blocking=True)
+        # ensemble-mean KE spectrum over ALL members of the job (comparison_tools.py:167-168)
+        from pyqg_generative_amd import parallel
+        local = e.diag('KEspec').sum(0)
+        if self.dist is not None and self.backend == 'gloo':
+            local = local.cpu()
+        self.mean_spec = parallel.ensemble_mean(local, e.B)
+        torch.cuda.current_stream().synchronize()
+        self.nsnap += 1
+
+    def run(self, n):
+        e = self.eng
+        done = 0
+        tc = e.tc
+        while done < n:
+            chunk = min(n - done, self.snap_every - tc % self.snap_every, self.status_every - tc % self.status_every)
+            e.step(chunk, **self.step_kw)
+            done += chunk
+            tc += chunk
+            if tc % self.status_every == 0:
+                ke, cfl = e.status()
+                assert np.isfinite(ke).all() and (cfl < 1).all(), 'CFL condition violated'
+                self.nstatus += 1
+            if tc % self.snap_every == 0:
+                self.snapshot()
+
+
+def timed(fn, barrier=lambda: None):
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def mfma_roofline(gen, precision, N, B, kname, traffic):
+    """roofline object of the dominant kernel (generator layer 2: 75 % of the FLOPs) from the HIP events the
+    library recorded around its launches inside the timed region"""
+    ms, n = gen.profile_read()
+    gen.profile(-1)
+    flop = 2.0 * MAC_PER_PIXEL[1] * N * N * B
+    avg_s = (ms / max(n, 1)) * 1e-3
+    achieved = flop / avg_s / 1e12 if avg_s > 0 else 0.0
+    mfma_per_mac = {'f32': 1, 'f16x3': 3, 'f16': 1}[precision]
+    peak = F32_MFMA_PEAK_TFLOPS if precision == 'f32' else F16_MFMA_PEAK_TFLOPS
+    r = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+         'frac': achieved / peak, 'traffic': traffic, 'flop_per_launch': flop, 'avg_launch_ms': avg_s * 1e3,
+         'launches_timed': n,
+         'peak_note': ('dense f32 MFMA peak; ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)' if precision == 'f32'
+                       else 'dense f16 MFMA peak; `achieved` counts ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)')}
+    if precision == 'f16x3':
+        r['mfma_pipe_frac'] = 3 * achieved / peak
+        r['mfma_pipe_note'] = ('f16x3 executes three f16 MFMAs per algorithmic multiply-add (hi*hi + hi*lo + lo*hi) to reach '
+                               'float32-class accuracy: executed MFMA flops = 3 x achieved')
+    return r
+
+
+def pmc_traffic(name, cfg):
+    """HBM bytes per launch of the roofline kernel: cannot be measured from inside this process, comes from
+    the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', name)) as f:
+            pt = json.load(f)
+        if pt['config'] == cfg:
+            return pt['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(N, kind, dt, target_seconds=15.0):
     """The CPU oracle (restatement of the reference's pyqg + PyTorch-CPU path) stepping ONE
     member sequentially, as the reference does, on this box's host cores."""
@@ -72,7 +178,8 @@ def cpu_baseline(N, kind, dt, target_seconds=15.0):
     m.noise_sampler = samplers_ref.make_sampler('constant', 1)
     m.q_parameterization = gen_ref.ParameterizationRef(ora, rng=np.random.RandomState(0))
     m.set_q(eddy_like_q([0], N)[0])
-    def timed(threads, seconds):
+
+    def run(threads, seconds):
         torch.set_num_threads(threads)
         for _ in range(3):
             m._step_forward()
@@ -88,8 +195,8 @@ def cpu_baseline(N, kind, dt, target_seconds=15.0):
     # the reference runs one member per 1-core process (scripts/run_parameterized.py:55-63);
     # also time the box's GPU-share of host cores (16 per GPU) and report the faster one
     share = max(1, min(16, os.cpu_count() or 1))
-    n1, el1 = timed(1, target_seconds / 2)
-    nm, elm = timed(share, target_seconds / 2)
+    n1, el1 = run(1, target_seconds / 2)
+    nm, elm = run(share, target_seconds / 2)
     r1, rm = n1 / el1, nm / elm
     best = (rm, share, nm, elm) if rm >= r1 else (r1, 1, n1, el1)
     return dict(value=best[0], unit='ensemble-timesteps/sec', cores=best[1], kind='port',
@@ -98,20 +205,91 @@ def cpu_baseline(N, kind, dt, target_seconds=15.0):
                 one_core=r1, cores_share=share, share_rate=rm)
 
 
+def leg_config3(qa, device, K, W):
+    """BASELINE configs[3]'s per-GPU shard: 96x96 jet + CVAE decoder, 32 members."""
+    N, B = 96, 32
+    dt = dt_of(N)
+    gen, _ = load_generator('vae', device)
+    eng = qa.EnsembleEngine(nx=N, n_members=B, device=device, dt=dt, **JET)
+    eng.set_q(eddy_like_q(np.arange(B), N))
+    loop = OnlineLoop(eng, dt, dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024))
+    loop.run(W)
+    gen.profile(1)
+    el = timed(lambda: loop.run(K))
+    roof = mfma_roofline(gen, 'f16x3', N, B, 'k_convh2<128,64,5x5> at 96x96 (generator layer 2)',
+                         pmc_traffic('pmc_traffic_config3.json', {'nx': N, 'members_per_gpu': B, 'kind': 'vae'}))
+    ke, cfl = eng.status()
+    out = {'workload': f'BASELINE configs[3] shard: jet {N}x{N} + CVAE, {B} members on 1 GPU (256 members / 8 GPUs), '
+                       f"sampling='constant' nsteps=1, dt={dt:.0f}s",
+           'value': B * K / el, 'unit': 'ensemble-timesteps/sec', 'steps': K, 'ms_per_step': 1e3 * el / K,
+           'roofline': roof, 'healthy': bool(np.isfinite(ke).all() and (cfl < 1).all())}
+    eng.close()
+    gen.close()
+    return out
+
+
+def leg_config4(qa, device, K, W):
+    """BASELINE configs[4]: 256x256 unparameterized hires members + the coarse-grain / subgrid-forcing
+    diagnostic to 64x64 (Operator2 and Operator5, 3/2-rule: simulate.py:88-92) at every snapshot."""
+    from pyqg_generative_amd.tools.operators import Dev
+    from pyqg_generative_amd import _lib
+    N, B, nc = 256, 64, 64
+    dt = dt_of(N)
+    eng = qa.EnsembleEngine(nx=N, n_members=B, device=device, dt=dt)
+    eng.set_q(eddy_like_q(np.arange(B), N))
+    eng.step(W)
+    pp = dict(qa.engine.PYQG_DEFAULTS)
+
+    def coarsegrain():
+        q = eng.get(_lib.F_Q)
+        for op in (Dev.Operator2, Dev.Operator5):
+            Dev.PV_subgrid_forcing(q, nc, op, pp, '3/2-rule')
+    coarsegrain()                                   # plan creation outside the timed region
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]   # qgx_step launches on torch's current stream
+
+    def body():
+        ev[0].record()
+        eng.step(K)
+        ev[1].record()
+        coarsegrain()
+    el = timed(body)
+    step_ms = ev[0].elapsed_time(ev[1]) / K
+    bytes_step = 5 * (2 * N * (N // 2 + 1) * 16) * B           # SURVEY §8(d): 5,283,840 B per member-step
+    achieved = bytes_step / (step_ms * 1e-3) / 1e9
+    snap = int(math.ceil(3.6e6 / dt))
+    ke, cfl = eng.status()
+    out = {'workload': f'BASELINE configs[4]: eddy {N}x{N} unparameterized, {B} members on 1 GPU, dt={dt:.0f}s; one '
+                       f'coarse-grain + 3/2-rule subgrid forcing to {nc}x{nc} (Operator2, Operator5) after the {K} timed steps',
+           'value': B * K / el, 'unit': 'ensemble-timesteps/sec (coarse-grain included once per timed run)',
+           'steps': K, 'ms_per_step': step_ms, 'coarsegrain_ms': 1e3 * el - step_ms * K,
+           'value_at_reference_cadence': B * snap / (step_ms * 1e-3 * snap + (el - step_ms * 1e-3 * K)),
+           'cadence_note': f'reference cadence: one coarse-grain per {snap} steps',
+           'roofline': {'bound': 'hbm', 'kernel': 'spectral step (5 launches of spectral_large.hip per step)',
+                        'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                        'traffic': pmc_traffic('pmc_traffic_config4.json', {'nx': N, 'members': B}),
+                        'bytes_per_step': bytes_step, 'avg_step_ms': step_ms,
+                        'peak_note': 'ALGORITHMIC bytes: read qh, dqhdt_p, dqhdt_pp + write qh, dqhdt = 5 x (2 N nk 16 B) per member-step'},
+           'healthy': bool(np.isfinite(ke).all() and (cfl < 1).all())}
+    eng.close()
+    Dev.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=2000, help='timed steps (SURVEY §8d: 2,000 after 100 warm-up)')
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--members', type=int, default=128, help='ensemble members PER GPU')
     ap.add_argument('--nx', type=int, default=64)
     ap.add_argument('--kind', default='gan', choices=['gan', 'vae', 'gz'])
     ap.add_argument('--precision', default='f16x3', choices=list(PRECISIONS),
                     help='generator conv arithmetic: f16x3 = hi/lo split f16 MFMA, f32-class accuracy (default); '
                          'f32 = exact f32 MFMA; f16 = plain f16 operands (TF32-class)')
-    ap.add_argument('--no-f32-aux', action='store_true')
+    ap.add_argument('--no-aux', action='store_true', help='skip exact_f32 / b1 / config3 / config4 legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-b1', action='store_true')
+    ap.add_argument('--leg', default='all', choices=['all', 'config3', 'config4'],
+                    help='profiling runs: only the named auxiliary leg (prints its JSON object)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + QGX_BENCH_ONE_DEVICE=1 rehearses the multi-rank path on a 1-GPU box")
     args = ap.parse_args()
@@ -136,7 +314,11 @@ def main():
 
     import pyqg_generative_amd as qa
     N, B, K, W = args.nx, args.members, args.steps, args.warmup
-    dt = 14400. if N <= 64 else (7200. if N <= 128 else 3600.)      # tools/parameters.py:12-31
+    if args.leg != 'all':
+        leg = {'config3': leg_config3, 'config4': leg_config4}[args.leg]
+        print(json.dumps({args.leg: leg(qa, local_rank, K, W)}))
+        return
+    dt = dt_of(N)
     gen, wsrc = load_generator(args.kind, local_rank)
     gen.set_option('precision', PRECISIONS[args.precision])
     eng = qa.EnsembleEngine(nx=N, n_members=B, device=local_rank, dt=dt)
@@ -144,23 +326,15 @@ def main():
     eng.set_q(eddy_like_q(ids, N))
     step_kw = dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024,
                    member_offset=rank * B)                           # run_parameterized.py:50
+    loop = OnlineLoop(eng, dt, step_kw, dist, args.backend)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    eng.step(W, **step_kw)
-    torch.cuda.synchronize()
+    loop.run(W)
     gen.profile(1)                      # dominant kernel: conv layer 2 (128->64, 5x5), 75% of the FLOPs
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.step(K, **step_kw)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    l2_ms, l2_n = gen.profile_read()
-    gen.profile(-1)
+    elapsed = timed(lambda: loop.run(K), barrier)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,32 +346,18 @@ def main():
     if rank == 0:
         total_members = B * world
         value = total_members * K / elapsed
-        flop_per_launch = 2.0 * MAC_PER_PIXEL[1] * N * N * B
-        avg_s = (l2_ms / max(l2_n, 1)) * 1e-3
-        achieved = flop_per_launch / avg_s / 1e12 if avg_s > 0 else 0.0
-        # HBM traffic of that kernel cannot be measured from inside this process: it comes from
-        # the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-        def pmc_traffic(name):
-            try:
-                with open(os.path.join(ROOT, 'profiles', name)) as f:
-                    pt = json.load(f)
-                if pt['config'] == {'nx': N, 'members_per_gpu': B, 'kind': args.kind}:
-                    return pt['traffic_bytes_per_launch']
-            except (OSError, KeyError, ValueError):
-                pass
-            return None
-        traffic = pmc_traffic('pmc_traffic.json')
-        traffic_h = pmc_traffic('pmc_traffic_f16x3.json')
+        cfg = {'nx': N, 'members_per_gpu': B, 'kind': args.kind}
+        traffic = {'f32': pmc_traffic('pmc_traffic.json', cfg), 'f16x3': pmc_traffic('pmc_traffic_f16x3.json', cfg),
+                   'f16': None}[args.precision]
+        kname = ('k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh2<128,64,5x5>') + ' (generator layer 2)'
+        roof = mfma_roofline(gen, args.precision, N, B, kname, traffic)
         gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
-        # peak for ALGORITHMIC flops: f16x3 executes three f16 MFMAs per algorithmic multiply-add
-        mfma_per_mac = {'f32': 1, 'f16x3': 3, 'f16': 1}[args.precision]
-        peak = F32_MFMA_PEAK_TFLOPS if args.precision == 'f32' else F16_MFMA_PEAK_TFLOPS / mfma_per_mac
+        roof['whole_step_generator_tflops'] = gen_flop_per_member_step * value / world / 1e12
         dtype = {'f32': 'f64 spectral core + f32 generator (exact-f32 MFMA)',
                  'f16x3': 'f64 spectral core + f32-class generator: f16 hi/lo split operands, 3 f16 MFMAs per '
                           'product, f32 accumulate (error vs a float64 ground truth <= the exact-f32 path, '
                           'tests/test_gpu_precision.py)',
                  'f16': 'f64 spectral core + f16-operand generator (f32 accumulate, TF32-class)'}[args.precision]
-        kname = 'k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh2<128,64,5x5>'
         out = {
             'metric': 'ensemble-timesteps/sec, 64^2 2-layer eddy + GAN param',
             'value': value, 'unit': 'ensemble-timesteps/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -209,52 +369,46 @@ def main():
                                    f"sampling='constant' nsteps=1, dt={dt:.0f}s",
                        'members_per_gpu': B, 'total_members': total_members, 'nx': N,
                        'generator_precision': args.precision,
+                       'cadence': {'diagnostics_every': int(math.ceil(86400. / dt)), 'snapshot_every': loop.snap_every,
+                                   'status_every': loop.status_every, 'snapshots_in_timed_region': None,
+                                   'status_checks_in_timed_region': None,
+                                   'ensemble_mean_spectrum': 'one all-reduce of (2,N,N/2+1) f64 per snapshot'},
                        'parallelism': f'ensemble-sharded x{world}, no data-path collective'},
-            'roofline': {'bound': 'mfma', 'kernel': f'{kname} (generator layer 2)',
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak,
-                         'traffic': traffic if args.precision == 'f32' else (traffic_h if args.precision == 'f16x3' else None),
-                         'flop_per_launch': flop_per_launch, 'avg_launch_ms': avg_s * 1e3,
-                         'launches_timed': l2_n,
-                         'executed_mfma_tflops': achieved * mfma_per_mac,
-                         'peak_note': ('157.3 TFLOP/s dense f32 MFMA' if args.precision == 'f32' else
-                                       f'2500 TFLOP/s dense f16 MFMA / {mfma_per_mac} MFMAs per algorithmic MAC; a bare '
-                                       'MFMA loop with this operand traffic sustains 1456 TFLOP/s on random data '
-                                       '(clock held at 1.66 GHz under load, bench_tools/mfma_peak_f16.hip)'),
-                         'whole_step_generator_tflops': gen_flop_per_member_step * value / world / 1e12},
+            'roofline': roof,
             'healthy': healthy,
         }
 
-    # the same workload on the exact-f32 matrix cores (auxiliary: round-to-round continuity)
-    if world == 1 and args.precision != 'f32' and not args.no_f32_aux:
+    aux = world == 1 and not args.no_aux
+    # the same workload on the exact-f32 matrix cores (auxiliary: same-precision-as-the-reference number)
+    if aux and args.precision != 'f32':
+        K32 = min(K, 200)
         gen.set_option('precision', 0)
-        eng.step(W, **step_kw)
-        torch.cuda.synchronize()
+        loop.run(5)
         gen.profile(1)
-        t0 = time.perf_counter()
-        eng.step(K, **step_kw)
-        torch.cuda.synchronize()
-        el32 = time.perf_counter() - t0
-        ms32, n32 = gen.profile_read()
-        gen.profile(-1)
+        el32 = timed(lambda: loop.run(K32))
+        r32 = mfma_roofline(gen, 'f32', N, B, 'k_conv<128,64,5x5> (generator layer 2)',
+                            pmc_traffic('pmc_traffic.json', {'nx': N, 'members_per_gpu': B, 'kind': args.kind}))
         gen.set_option('precision', PRECISIONS[args.precision])
-        a32 = 2.0 * MAC_PER_PIXEL[1] * N * N * B / ((ms32 / max(n32, 1)) * 1e-3) / 1e12
-        out['exact_f32'] = {'value': B * K / el32, 'unit': 'ensemble-timesteps/sec', 'ms_per_step': 1e3 * el32 / K,
-                            'roofline': {'bound': 'mfma', 'kernel': 'k_conv<128,64,5x5> (generator layer 2)',
-                                         'achieved': a32, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                         'frac': a32 / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic}}
+        out['exact_f32'] = {'value': B * K32 / el32, 'unit': 'ensemble-timesteps/sec', 'steps': K32,
+                            'ms_per_step': 1e3 * el32 / K32, 'roofline': r32}
+    if rank == 0:
+        # counted over warm-up + timed (+ the f32 leg); the timed region's share follows from the cadences
+        out['config']['cadence']['snapshots_in_timed_region'] = (W + K) // loop.snap_every - W // loop.snap_every
+        out['config']['cadence']['status_checks_in_timed_region'] = (W + K) // 1000 - W // 1000
 
-    # configs[1]: the single-member, launch-latency-bound case (auxiliary number)
-    if world == 1 and not args.no_b1:
+    # configs[1]: the single-member, launch-latency-bound case
+    if aux:
+        K1 = min(4 * K, 2000)
         e1 = qa.EnsembleEngine(nx=N, n_members=1, device=local_rank, dt=dt)
         e1.set_q(eddy_like_q([0], N))
-        e1.step(W, **step_kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        e1.step(4 * K, **step_kw)
-        torch.cuda.synchronize()
-        out['b1'] = {'workload': 'BASELINE configs[1]: 1 member on 1 GPU (latency-bound)',
-                     'value': 4 * K / (time.perf_counter() - t0), 'unit': 'ensemble-timesteps/sec'}
+        l1 = OnlineLoop(e1, dt, dict(step_kw, member_offset=0))
+        l1.run(W)
+        el1 = timed(lambda: l1.run(K1))
+        out['b1'] = {'workload': 'BASELINE configs[1]: 64x64 eddy + CGAN, 1 member on 1 GPU (launch-latency-bound)',
+                     'value': K1 / el1, 'unit': 'ensemble-timesteps/sec', 'steps': K1, 'ms_per_step': 1e3 * el1 / K1}
+        e1.close()
+        out['config3'] = leg_config3(qa, local_rank, min(K, 200), min(W, 10))
+        out['config4'] = leg_config4(qa, local_rank, min(K, 100), min(W, 5))
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(N, args.kind, dt)

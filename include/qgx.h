@@ -72,7 +72,8 @@ enum qgx_field {               /* pyqg attribute of the same name */
     QGX_F_DQHDT_P = 6,
     QGX_F_DQHDT_PP = 7,
     QGX_F_S = 8,      /* real: subgrid forcing used by the last step (m.PV_forcing) */
-    QGX_F_Z = 9       /* latent noise held by the sampler (float or double)     */
+    QGX_F_Z = 9,      /* latent noise held by the sampler (float or double)     */
+    QGX_F_P = 10      /* m.p      real: irfft2(ph), pyqg's derived streamfunction (to_dataset 'p') */
 };
 
 enum qgx_table {               /* grid constants, (N, N/2+1) double unless noted */

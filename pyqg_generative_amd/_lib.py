@@ -38,7 +38,7 @@ class qgx_cnn_weights(C.Structure):
 
 
 # enum mirrors (include/qgx.h)
-F_Q, F_QH, F_PH, F_U, F_V, F_DQHDT, F_DQHDT_P, F_DQHDT_PP, F_S, F_Z = range(10)
+F_Q, F_QH, F_PH, F_U, F_V, F_DQHDT, F_DQHDT_P, F_DQHDT_PP, F_S, F_Z, F_P = range(11)
 T_FILTR, T_WV2, T_A, T_KK, T_LL = range(5)
 SAMPLING_AR1, SAMPLING_CONSTANT = 0, 1
 DIAGS = ['KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec', 'paramspec',

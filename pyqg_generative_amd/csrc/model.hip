@@ -260,7 +260,7 @@ extern "C" size_t qgx_field_bytes(const qgx_model *m, int field) {
     if (!m) return 0;
     const size_t nr = (size_t)m->B * 2 * m->N * m->N, ns = (size_t)m->B * 2 * m->N * m->NK;
     switch (field) {
-        case QGX_F_Q: case QGX_F_U: case QGX_F_V: case QGX_F_S: return nr * sizeof(double);
+        case QGX_F_Q: case QGX_F_U: case QGX_F_V: case QGX_F_S: case QGX_F_P: return nr * sizeof(double);
         case QGX_F_QH: case QGX_F_PH: case QGX_F_DQHDT: case QGX_F_DQHDT_P: case QGX_F_DQHDT_PP:
             return ns * sizeof(double2);
         case QGX_F_Z: return nr * (m->z_double ? sizeof(double) : sizeof(float));
@@ -270,6 +270,9 @@ extern "C" size_t qgx_field_bytes(const qgx_model *m, int field) {
 
 extern "C" int qgx_get(qgx_model *m, int field, void *out_dev, void *stream) {
     QGX_REQUIRE(m && out_dev, "qgx_get: null argument");
+    if (field == QGX_F_P)      // pyqg's derived field p = ifft(ph) (model.py::_calc_derived_fields), straight into the caller's buffer
+        return m->small ? small_qh_to_q(m->d, m->ph, (double *)out_dev, (hipStream_t)stream)
+                        : large_qh_to_q(m, m->ph, (double *)out_dev, (hipStream_t)stream);
     const void *src = nullptr;
     switch (field) {
         case QGX_F_Q: src = m->q; break;

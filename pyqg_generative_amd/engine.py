@@ -141,7 +141,7 @@ class EnsembleEngine:
         return torch.empty((self.B, 2, self.N, self.NK), dtype=torch.complex128, device=self.device)
 
     def get(self, field, noise_dtype=torch.float32):
-        if field in (_lib.F_Q, _lib.F_U, _lib.F_V, _lib.F_S):
+        if field in (_lib.F_Q, _lib.F_U, _lib.F_V, _lib.F_S, _lib.F_P):
             out = self._real()
         elif field == _lib.F_Z:
             out = torch.empty((self.B, 2, self.N, self.N), dtype=noise_dtype, device=self.device)

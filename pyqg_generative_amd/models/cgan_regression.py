@@ -15,15 +15,42 @@ class _LatentCNN(Parameterization):
     def generate_latent_noise(self, ny, nx):
         return np.random.randn(1, self.n_latent, ny, nx).astype('float32')
 
-    def predict_mean_snapshot(self, m, M=100):
+    def predict_mean_snapshot(self, m, M=100, seed=None):
+        """Deterministic sampling: the mean of M forcing realisations for ONE PV snapshot
+        (cgan_regression.py:164-171, cvae_regression.py:138-145).  seed=None draws the latent noise from
+        numpy's global stream as the reference does; an integer seed draws realisation j on the device from
+        the Philox stream (seed, counter j), which the oracle reproduces (tests)."""
         q = np.asarray(m.q, dtype='float64')
         if q.ndim != 3:
             raise ValueError('predict_mean_snapshot expects a single member (2,N,N)')
+        N = q.shape[-1]
         X = self.x_scale.normalize(q.astype('float32'))                  # (1,2,N,N)
-        z = np.random.randn(M, self.n_latent, q.shape[-2], q.shape[-1]).astype('float32')
-        Y = apply_function(self._gen, np.tile(X, (M, 1, 1, 1)), z).mean(0, keepdims=True)
+        if seed is None:
+            z = np.random.randn(M, self.n_latent, q.shape[-2], N).astype('float32')
+            Y = apply_function(self._gen, np.tile(X, (M, 1, 1, 1)), z).mean(0, keepdims=True)
+        else:
+            from .._lib import lib, check
+            from ..engine import _ptr, _stream
+            x = torch.empty((M, 4, N, N), dtype=torch.float32, device='cuda')
+            x[:, :2] = torch.as_tensor(np.ascontiguousarray(X)).cuda()
+            z = torch.empty((M, 2, N, N), dtype=torch.float32, device='cuda')
+            check(lib.qgx_noise_normal(_ptr(z), 0, M, 2 * N * N, int(seed), 0, 0, 0.0, 1.0, _stream()))
+            x[:, 2:] = z
+            Y = self._gen.cnn_forward(x).to(torch.float64).mean(0, keepdim=True).cpu().numpy().astype('float32')
         return self.y_scale.denormalize(Y).squeeze().astype('float64')
 
+    def predict(self, ds, M=1000, seed=0):
+        """Offline Monte-Carlo prediction for a dataset with q (run, time, lev, y, x)
+        (cgan_regression.py:173-189, cvae_regression.py:147-163): one sample, the mean and the variance
+        of M realisations per snapshot."""
+        from ..tools.simulate import dataset_backend
+        xr = dataset_backend()
+        qv = np.asarray(ds['q'].values)
+        Y, mean, var = self.generate_mean_var(qv.reshape((-1,) + qv.shape[2:]), M=M, seed=seed)
+        dims = ['run', 'time', 'lev', 'y', 'x']
+        return xr.Dataset({'q_forcing_advection': (dims, Y.reshape(qv.shape)),
+                           'q_forcing_advection_mean': (dims, mean.reshape(qv.shape)),
+                           'q_forcing_advection_var': (dims, var.reshape(qv.shape))})
 
     def generate_mean_var(self, q, M=1000, seed=0, batch_size=64):
         """Offline Monte-Carlo sampling (reference: generate_mean_var + predict,

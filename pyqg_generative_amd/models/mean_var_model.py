@@ -22,3 +22,17 @@ class MeanVarModel(Parameterization):
     def predict_mean_snapshot(self, m, M=100):
         X = self.x_scale.normalize(np.asarray(m.q, 'float64').astype('float32'))
         return self.y_scale.denormalize(apply_function(self._gen, X, inet=0)).squeeze().astype('float64')
+
+    def predict(self, ds, M=1000, seed=None):
+        """mean_var_model.py:117-135: mean net, softplus variance net, one Gaussian sample."""
+        from ..tools.simulate import dataset_backend
+        xr = dataset_backend()
+        qv = np.asarray(ds['q'].values)
+        X = self.x_scale.normalize(qv.reshape((-1,) + qv.shape[2:]).astype('float32'))
+        mean = self.y_scale.denormalize(apply_function(self._gen, X, inet=0)).reshape(qv.shape)
+        var = self.y_scale.denormalize_var(np.logaddexp(0, apply_function(self._gen, X, inet=1))).reshape(qv.shape)
+        rng = np.random if seed is None else np.random.RandomState(seed)
+        Y = mean + np.sqrt(var) * rng.randn(*var.shape)
+        dims = ['run', 'time', 'lev', 'y', 'x']
+        return xr.Dataset({'q_forcing_advection': (dims, Y), 'q_forcing_advection_mean': (dims, mean),
+                           'q_forcing_advection_var': (dims, var)})

@@ -69,6 +69,7 @@ class QGModel:
         self.rek, self.filterfac, self.beta, self.rd, self.delta = rek, filterfac, beta, rd, delta
         self.H1, self.U1, self.U2 = H1, U1, U2
         self.log_level = log_level
+        self.ntd = 1                      # pyqg: FFTW threads; exported as the attribute pyqg:ntd
         self.n_members = int(n_members)
         self.seed, self.member_offset = int(seed), int(member_offset)
         self.q_parameterization = q_parameterization or parameterization
@@ -158,9 +159,19 @@ class QGModel:
     ufull = property(lambda self: self.u + self.Ubg[:, None, None])
     vfull = property(lambda self: self.v)
 
+    p = property(lambda self: self._host(_lib.F_P))      # irfft2(ph) on the device (pyqg: _calc_derived_fields)
+
     @property
-    def p(self):
-        return self.ifft(self.ph)
+    def uh(self):                                         # kernel.pyx::_invert: uh = -il ph, vh = ik ph
+        return -self.il * self.ph
+
+    @property
+    def vh(self):
+        return self.ik * self.ph
+
+    @property
+    def dqdt(self):
+        return self.ifft(self.dqhdt)
 
     @property
     def tc(self):
@@ -299,7 +310,15 @@ class QGModel:
         return self._eng.diag_count
 
     def _calc_derived_fields(self):
-        pass    # p is derived on access; the remaining derived fields feed diagnostics not built yet
+        pass    # pyqg caches p, xi, Jptpc ... here; this facade derives p / uh / vh / dqdt on access
+
+    def to_dataset(self, variables=None):
+        """pyqg's Model.to_dataset(): state (+ time-averaged diagnostics once t >= tavestart) in pyqg's
+        xarray layout (xarray_output.py; reference call sites simulate.py:93,105,133,138).  ``variables``
+        restricts the exported state fields (run_simulation exports only what survives drop_vars)."""
+        from . import xarray_output
+        names = xarray_output.VARIABLES if variables is None else variables
+        return xarray_output.model_to_dataset(self, fields={n: getattr(self, n) for n in names})
 
     def close(self):
         self._eng.close()

@@ -10,6 +10,7 @@ tensors so that a pipeline (e.g. generate_subgrid_forcing) never leaves the GPU.
 arithmetic is in libqgx.so (qgx_rfft2 / qgx_irfft2 / qgx_spec_regrid / qgx_spec_div /
 qgx_real_fma); torch only owns the buffers.
 """
+import collections
 import ctypes as C
 import math
 import numpy as np
@@ -24,18 +25,49 @@ FILTER_2h_HARMONICS = True
 
 
 class Dev:
-    """Operators on device tensors of shape (M, N, N) float64 (M fields) / (M, N, N/2+1) complex128."""
+    """Operators on device tensors of shape (M, N, N) float64 (M fields) / (M, N, N/2+1) complex128.
+
+    FFT plans and inversion models are engines (device allocations) kept in ONE keyed LRU cache:
+    ('fft', N, M, device) or ('inv', N, B, device, params).  ``Dev.close()`` frees everything;
+    the least recently used engine is closed when more than ``MAX_PLANS`` are alive, so sweeping many
+    resolutions x operators (generate_subgrid_forcing) does not accumulate device memory."""
     L = 1e6
-    _plans = {}
+    MAX_PLANS = 12
+    _plans = collections.OrderedDict()
     _tables = {}
+    _PARAM_KEYS = ('rek', 'delta', 'beta', 'rd', 'U1', 'U2', 'H1', 'L')
 
     # ---- plumbing ---------------------------------------------------------------------------
     @classmethod
+    def _engine(cls, key, make):
+        e = cls._plans.get(key)
+        if e is None:
+            e = cls._plans[key] = make()
+            while len(cls._plans) > cls.MAX_PLANS:
+                _, old = cls._plans.popitem(last=False)
+                old.close()
+        else:
+            cls._plans.move_to_end(key)
+        return e
+
+    @classmethod
     def plan(cls, N, M, device=0):
-        key = (N, M, device)
-        if key not in cls._plans:
-            cls._plans[key] = EnsembleEngine(nx=N, n_members=M // 2, device=device, L=cls.L)
-        return cls._plans[key]
+        return cls._engine(('fft', N, M, device),
+                           lambda: EnsembleEngine(nx=N, n_members=M // 2, device=device, L=cls.L))
+
+    @classmethod
+    def inversion_model(cls, N, B, device, pyqg_params):
+        """the cached engine that inverts (B,2,N,N) PV fields with these physical parameters"""
+        kw = {k: v for k, v in pyqg_params.items() if k in cls._PARAM_KEYS}
+        return cls._engine(('inv', N, B, device, tuple(sorted(kw.items()))),
+                           lambda: EnsembleEngine(nx=N, n_members=B, device=device, **kw))
+
+    @classmethod
+    def close(cls):
+        for e in cls._plans.values():
+            e.close()
+        cls._plans.clear()
+        cls._tables.clear()
 
     @classmethod
     def table(cls, N, name, device=0):
@@ -178,32 +210,29 @@ class Dev:
         raise ValueError('dealias should be none or 2/3-rule or 3/2-rule')
 
     @classmethod
-    def velocities(cls, q, pyqg_params):
+    def velocities(cls, q, pyqg_params, return_engine=False):
         """(u, v) of PV fields q (B,2,N,N) by the model's inversion (apply_operator_to_model,
         operators.py:229-234 builds a fresh pyqg model per call; here one cached engine per grid)."""
         B, _, N, _ = q.shape
-        key = ('inv', N, B, q.device.index or 0, tuple(sorted((k, v) for k, v in pyqg_params.items()
-                                                              if k in ('rek', 'delta', 'beta', 'rd', 'U1', 'U2', 'H1', 'L'))))
-        if key not in cls._plans:
-            kw = {k: v for k, v in pyqg_params.items() if k in ('rek', 'delta', 'beta', 'rd', 'U1', 'U2', 'H1', 'L')}
-            cls._plans[key] = EnsembleEngine(nx=N, n_members=B, device=q.device.index or 0, **kw)
-        e = cls._plans[key]
+        e = cls.inversion_model(N, B, q.device.index or 0, pyqg_params)
         e.set_q(q)
         e.invert()
-        return e.get(_lib.F_U), e.get(_lib.F_V)
+        u, v = e.get(_lib.F_U), e.get(_lib.F_V)
+        return (u, v, e) if return_engine else (u, v)
 
     @classmethod
-    def PV_subgrid_forcing(cls, q, nc, operator, pyqg_params, dealias='none'):
-        """q: (B,2,N,N) device tensor.  -> (forcing, qf, uf, vf) on the nc grid, each (B,2,nc,nc)."""
+    def PV_subgrid_forcing(cls, q, nc, operator, pyqg_params, dealias='none', return_psi=False):
+        """q: (B,2,N,N) device tensor.  -> (forcing, qf, uf, vf [, psi_f]) on the nc grid, each (B,2,nc,nc)."""
         B, _, N, _ = q.shape
         flat = lambda t: t.reshape(-1, t.shape[-2], t.shape[-1])
         u, v = cls.velocities(q, pyqg_params)
         qf = operator(flat(q), nc).reshape(B, 2, nc, nc)
-        uf, vf = cls.velocities(qf, pyqg_params)
+        uf, vf, coarse = cls.velocities(qf, pyqg_params, return_engine=True)
+        psi = coarse.get(_lib.F_P) if return_psi else None      # before the engine is reused / evicted
         adv_c = cls.advect(flat(qf), flat(uf), flat(vf), dealias)
         adv_f = operator(cls.advect(flat(q), flat(u), flat(v), dealias), nc)
         forcing = cls.mul(adv_c, None, 1.0, adv_f, -1.0).reshape(B, 2, nc, nc)
-        return forcing, qf, uf, vf
+        return (forcing, qf, uf, vf, psi) if return_psi else (forcing, qf, uf, vf)
 
 
 # ---- numpy-facing functions with the reference's names ------------------------------------------

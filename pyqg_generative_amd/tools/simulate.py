@@ -9,7 +9,7 @@ n_members > 1.
 import numpy as np
 
 from ..qgmodel import QGModel
-from .parameters import ANDREW_1000_STEPS
+from .parameters import ANDREW_1000_STEPS, DAY
 from .stochastic_pyqg import stochastic_QGModel
 
 
@@ -45,40 +45,46 @@ def set_initial_condition(m, seeds=None):
     m._invert()
 
 
-def snapshot_dataset(m):
-    """The part of pyqg's Model.to_dataset() that survives drop_vars: q, u, v, psi as float32
-    (time, [run,] lev, y, x) with pyqg's coordinates; time in days."""
-    xr = dataset_backend()
-    B = m.n_members
-    lead = ('time',) if B == 1 else ('time', 'run')
-    dims = lead + ('lev', 'y', 'x')
-    f32 = lambda a: np.asarray(a, dtype='float32')[None]
-    data = {'q': (dims, f32(m.q)), 'u': (dims, f32(m.u)), 'v': (dims, f32(m.v)), 'psi': (dims, f32(m.p))}
-    coords = {'time': ('time', np.array([m.t / 86400.], dtype='float32')),
-              'lev': ('lev', np.arange(1, 3)),
-              'x': ('x', m.x[0, :].astype('float32')), 'y': ('y', m.y[:, 0].astype('float32'))}
-    if B > 1:
-        coords['run'] = ('run', np.arange(m.member_offset, m.member_offset + B))
-    if xr.__name__.endswith('xr_lite'):
-        ds = xr.Dataset(data, coords={k: xr.DataArray(v[1], [v[0]]) for k, v in coords.items()})
-    else:
-        ds = xr.Dataset({k: (v[0], v[1]) for k, v in data.items()}, coords=coords)
-    # time-averaged spectral diagnostics, present once averaging has started (t >= tavestart)
-    if m.diagnostics_count > 0:
-        run = () if B == 1 else ('run',)
-        for name in m.diagnostic_names:
-            a = np.asarray(m.get_diagnostic(name), dtype='float32')
-            dd = run + (('lev', 'l', 'k') if a.ndim - len(run) == 3 else ('l', 'k'))
-            ds[name] = xr.DataArray(a, dd) if xr.__name__.endswith('xr_lite') else (dd, a)
-    ds['time'].attrs['units'] = 'days'
-    ds.attrs.update({'pyqg:nx': m.nx, 'pyqg:dt': m.dt, 'pyqg:rek': m.rek, 'pyqg:delta': m.delta,
-                     'pyqg:beta': m.beta, 'pyqg:L': m.L, 'pyqg:rd': m.rd})
+SNAPSHOT_VARIABLES = ('q', 'u', 'v', 'p')       # the state fields that survive drop_vars
+
+
+def drop_vars(ds):
+    """Drop complex variables and the redundant real ones, convert float64 to float32, rename
+    p -> psi, express time in days (reference: simulate.py:16-36)."""
+    for key, var in ds.variables.items():
+        if var.dtype == np.float64:
+            ds[key] = var.astype(np.float32)
+        elif var.dtype == np.complex128:
+            ds = ds.drop_vars(key)
+    for key in ('dqdt', 'ufull', 'vfull'):
+        if key in ds.keys():
+            ds = ds.drop_vars([key])
+    if 'p' in ds.keys():
+        ds = ds.rename({'p': 'psi'})
+    if ds['time'].attrs.get('units') != 'days':
+        ds['time'] = ds['time'].values / 86400
+        ds['time'].attrs['units'] = 'days'
     return ds
 
 
 def concat_in_time(datasets):
+    """Snapshots -> one dataset (reference: simulate.py:39-60): state variables are concatenated along
+    'time'; the spectral diagnostics are running time averages, so they are taken from the LAST snapshot
+    (early snapshots, taken before tavestart, do not have them)."""
     xr = dataset_backend()
-    return xr.concat(datasets, dim='time')
+    last = datasets[-1]
+    common = [k for k in datasets[0].keys() if all(k in d.keys() for d in datasets)]
+    ds = xr.concat([d[common] for d in datasets], dim='time')
+    for key in last.keys():
+        if 'k' in last[key].dims:
+            ds[key] = last[key].isel(time=-1)
+    return drop_vars(ds)
+
+
+def snapshot_dataset(m):
+    """One snapshot as run_simulation stores it: ``drop_vars(m.to_dataset())`` (simulate.py:133,138),
+    exporting only the fields drop_vars keeps."""
+    return drop_vars(m.to_dataset(variables=SNAPSHOT_VARIABLES))
 
 
 def run_simulation(pyqg_params, parameterization=None, q_init=None, sampling_freq=ANDREW_1000_STEPS,
@@ -86,7 +92,7 @@ def run_simulation(pyqg_params, parameterization=None, q_init=None, sampling_fre
     """pyqg_params: dict of model parameters; parameterization: None or
     dict(self=<Parameterization>, sampling='AR1'|'constant'|'deterministic', nsteps=int);
     q_init: optional PV (nlev,ny,nx) or (B,nlev,ny,nx).  Returns a Dataset of snapshots taken
-    every ``sampling_freq`` seconds of model time."""
+    every ``sampling_freq`` seconds of model time (reference: simulate.py:109-145)."""
     params = dict(pyqg_params)
     params['tmax'] = float(params['tmax'])
     eng = dict(n_members=n_members, device=device, seed=seed, member_offset=member_offset)
@@ -115,11 +121,10 @@ def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n
     """Forcing-dataset generation (reference: simulate.py:62-106): run the high-resolution model given
     by pyqg_params and, every ``sampling_freq`` seconds, coarse-grain the PV to each resolution in Nc
     with each operator and diagnose the subgrid forcing with 3/2-rule dealiasing.  Returns
-    {'<Operator>-<nc>-dealias': Dataset(q_forcing_advection, q, u, v, psi  float32 (time,[run,]lev,y,x))}.
+    {'<Operator>-<nc>-dealias': Dataset(q_forcing_advection, q, u, v, psi  float32 ([run,]time,lev,y,x))}.
     The hires members, the coarse-graining and the forcing diagnostic all stay on the GPU."""
     import torch
     from .operators import Dev
-    from .. import _lib
     xr = dataset_backend()
     params = dict(pyqg_params)
     params['tmax'] = float(params['tmax'])
@@ -127,56 +132,54 @@ def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n
     set_initial_condition(m, seeds)
     coarse_params = {k: v for k, v in params.items() if k in ('rek', 'delta', 'beta', 'rd', 'U1', 'U2', 'H1', 'L')}
     B = n_members
-    lead = ('time',) if B == 1 else ('time', 'run')
-    dims = lead + ('lev', 'y', 'x')
+    dims = (('run',) if B > 1 else ()) + ('time', 'lev', 'y', 'x')
+    pack = lambda t: (t[:, None] if B > 1 else t).to(torch.float32).cpu().numpy()      # length-one time axis
     out = {}
     for _ in m.run_with_snapshots(tsnapint=sampling_freq):
         qd = m.q_device()
         for opname in operators:
             dev_op = getattr(Dev, opname)
             for nc in Nc:
-                forcing, qf, uf, vf = Dev.PV_subgrid_forcing(qd, nc, dev_op, coarse_params, '3/2-rule')
-                plan = Dev._plans[next(k for k in Dev._plans if k[0] == 'inv' and k[1] == nc and k[2] == B)]
-                ph = plan.get(_lib.F_PH).reshape(-1, nc, nc // 2 + 1)
-                psi = Dev.irfft2(ph).reshape(B, 2, nc, nc)
-                pack = lambda t: (t[0] if B == 1 else t).to(torch.float32).cpu().numpy()[None]
+                forcing, qf, uf, vf, psi = Dev.PV_subgrid_forcing(qd, nc, dev_op, coarse_params, '3/2-rule',
+                                                                  return_psi=True)
                 data = {'q_forcing_advection': (dims, pack(forcing)), 'q': (dims, pack(qf)),
                         'u': (dims, pack(uf)), 'v': (dims, pack(vf)), 'psi': (dims, pack(psi))}
                 xc = ((np.arange(nc) + 0.5) / nc * m.L).astype('float32')
-                coords = {'time': np.array([m.t / 86400.], dtype='float32'), 'lev': np.arange(1, 3), 'x': xc, 'y': xc}
-                if xr.__name__.endswith('xr_lite'):
-                    ds = xr.Dataset(data, coords={k: xr.DataArray(v, [k]) for k, v in coords.items()})
-                else:
-                    ds = xr.Dataset(data, coords={k: (k, v) for k, v in coords.items()})
-                ds['time'].attrs['units'] = 'days'
-                out.setdefault(f'{opname}-{nc}-dealias', []).append(ds)
+                coords = {'time': (('time',), np.array([m.t / 86400.], dtype='float32'), {'units': 'days'}),
+                          'lev': (('lev',), np.arange(1, 3)), 'x': (('x',), xc), 'y': (('y',), xc)}
+                if B > 1:
+                    coords['run'] = (('run',), np.arange(m.member_offset, m.member_offset + B))
+                out.setdefault(f'{opname}-{nc}-dealias', []).append(xr.Dataset(data, coords=coords))
+    attrs = dict(m.to_dataset(variables=()).attrs)          # simulate.py:105: the hires model's pyqg:* attributes
+    attrs['pyqg_params'] = str(pyqg_params)
     for key in out:
-        out[key] = xr.concat(out[key], 'time').assign_attrs({'pyqg_params': str(pyqg_params)})
+        out[key] = xr.concat(out[key], 'time').assign_attrs(attrs)
     m.close()
+    Dev.close()
     return out
 
 
-def run_forecast(pyqg_params, parameterization, q_init, n_ens, sampling_freq=86400, device=0, seed=0):
-    """Forecast mode (reference: simulate.py:254-293): n_ens members start from the SAME coarse-grained
-    initial PV and differ only in the latent noise; the reference runs them one after another and averages
-    with xarray, here they advance together.  Returns a Dataset holding q,u,v,psi of member 0 and the
-    ensemble means q_mean,u_mean,v_mean,psi_mean (time,lev,y,x)."""
+def run_forecast(pyqg_params, parameterization, q_init, n_ens, operator=None, sampling_freq=DAY, device=0, seed=0):
+    """Forecast mode (reference: simulate.py:254-293): the initial PV is a snapshot of a high-resolution
+    run, coarse-grained to the model's grid with ``operator`` ('Operator1' | 'Operator2' | 'Operator4' |
+    'Operator5' or the function itself; None / failure to apply = ``q_init`` is used as it is, as the
+    reference's try/except does, simulate.py:269-273); ``n_ens`` members start from it and differ only in
+    the latent noise.  The reference runs them one after another and averages with xarray
+    (simulate.py:279-290); here they advance together on the GPU.  Returns a Dataset holding q, u, v, psi
+    of member 0 and the ensemble means q_mean, u_mean, v_mean, psi_mean, each (time, lev, y, x)."""
     xr = dataset_backend()
+    q_init = np.asarray(q_init, dtype='float64')
+    nx = int(pyqg_params['nx'])
+    if operator is not None and q_init.shape[-1] != nx:
+        from . import operators as ops
+        op = getattr(ops, operator) if isinstance(operator, str) else operator
+        q_init = op(q_init, nx)
     ds = run_simulation(pyqg_params, parameterization, q_init=q_init, sampling_freq=sampling_freq,
-                        n_members=n_ens, device=device, seed=seed)
-    out = xr.Dataset(coords={k: ds[k] for k in ('time', 'lev', 'x', 'y')}) if not xr.__name__.endswith('xr_lite') \
-        else xr.Dataset(coords={k: ds[k] for k in ('time', 'lev', 'x', 'y')})
+                        n_members=n_ens, device=device, seed=seed)[['q', 'u', 'v', 'psi']]
+    if n_ens == 1:
+        ds = ds.expand_dims('run')
+    out = xr.Dataset(attrs=dict(ds.attrs))
     for var in ('q', 'u', 'v', 'psi'):
-        a = np.asarray(ds[var].values)
-        if n_ens == 1:
-            a = a[:, None]
-        dims = ('time', 'lev', 'y', 'x')
-        first, mean = a[:, 0], a.mean(axis=1)
-        if xr.__name__.endswith('xr_lite'):
-            out[var] = xr.DataArray(first, dims)
-            out[var + '_mean'] = xr.DataArray(mean, dims)
-        else:
-            out[var] = (dims, first)
-            out[var + '_mean'] = (dims, mean)
-    out.attrs.update(ds.attrs)
+        out[var] = ds[var].isel(run=0)
+        out[var + '_mean'] = ds[var].mean('run')
     return out

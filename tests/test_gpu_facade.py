@@ -149,9 +149,10 @@ def test_run_simulation_with_cgan_ensemble(tmp_path):
     ds = run_simulation(dict(params), parameterization=dict(self=0.5 * model, sampling='constant', nsteps=1),
                         sampling_freq=14400. * 10, n_members=3, seeds=[0, 1, 2], seed=7)
     q = np.asarray(ds['q'].values)
-    assert q.shape == (4, 3, 2, 64, 64) and q.dtype == np.float32
+    assert q.shape == (3, 4, 2, 64, 64) and q.dtype == np.float32      # (run, time, lev, y, x): the reference's stored layout
+    assert ds['q'].dims == ('run', 'time', 'lev', 'y', 'x')
     np.testing.assert_allclose(np.asarray(ds['time'].values), np.array([10, 20, 30, 40]) * 14400. / 86400.)
-    assert np.isfinite(q).all() and np.abs(q[-1, 0] - q[-1, 1]).max() > 0
+    assert np.isfinite(q).all() and np.abs(q[0, -1] - q[1, -1]).max() > 0
     # a second run with the same seeds reproduces the trajectory bit for bit
     ds2 = run_simulation(dict(params), parameterization=dict(self=0.5 * model, sampling='constant', nsteps=1),
                          sampling_freq=14400. * 10, n_members=3, seeds=[0, 1, 2], seed=7)
@@ -174,24 +175,159 @@ def test_unparameterized_run_simulation_matches_oracle_config1():
     assert np.abs(q[-1] - m.q).max() < 1e-6 * np.abs(m.q).max()
 
 
-def test_forecast_mode_ensemble_mean(tmp_path):
-    """reference simulate.py:254-293: members share the initial condition, differ in noise; output =
-    member 0 and the ensemble mean."""
+class _PhiloxRng:
+    """feeds the oracle the device's latent-noise stream: draw j of member `member` = Philox(seed, member, j)"""
+
+    def __init__(self, seed, member):
+        self.seed, self.member, self.step = seed, member, 0
+
+    def randn(self, *shape):
+        x, _ = samplers_ref.philox_normal(self.seed, self.member, self.step, int(np.prod(shape)))
+        self.step += 1
+        return x.astype('float64').reshape(shape)
+
+
+def test_forecast_mode_matches_oracle(tmp_path):
+    """reference simulate.py:254-293: a hires snapshot is coarse-grained with an Operator (:270), n_ens
+    members start from it and differ in the latent noise (AR1, nsteps=10: run_forecasting.py:30,38);
+    output = member 0 and the ensemble mean.  Member 0 and the mean against the CPU oracle driven with the
+    same Philox draws."""
+    from oracle import operators_ref
     from pyqg_generative_amd.models import CVAERegression
     from pyqg_generative_amd.tools.simulate import run_forecast
     from pyqg_generative_amd.tools.parameters import EDDY_PARAMS
     model = CVAERegression(folder=_model_folder(tmp_path, 'vae'))
-    ref = qg_ref.QGModelRef(nx=48)
+    Nh, N, n_ens, seed, ndays = 96, 48, 3, 3, 2
+    hi = qg_ref.QGModelRef(nx=Nh)
     rs = np.random.RandomState(8)
-    q_init = np.fft.irfftn(np.fft.rfftn(rs.randn(2, 48, 48) * np.array([8e-6, 1e-6])[:, None, None], axes=(-2, -1))
-                           * (ref.wv < 2 / 3 * ref.kk[-1]), axes=(-2, -1)) * 3
-    params = EDDY_PARAMS.nx(48)._update({'tmax': 86400. * 3, 'log_level': 0})
-    out = run_forecast(dict(params), dict(self=model, sampling='AR1', nsteps=10), q_init, n_ens=5, seed=3)
+    q_hires = np.fft.irfftn(np.fft.rfftn(rs.randn(2, Nh, Nh) * np.array([8e-6, 1e-6])[:, None, None], axes=(-2, -1))
+                            * (hi.wv < 2 / 3 * hi.kk[-1]), axes=(-2, -1)) * 3
+    params = EDDY_PARAMS.nx(N)._update({'tmax': 86400. * ndays, 'log_level': 0})
+    out = run_forecast(dict(params), dict(self=model, sampling='AR1', nsteps=10), q_hires, n_ens=n_ens,
+                       operator='Operator2', seed=seed)
     q, qm = np.asarray(out['q'].values), np.asarray(out['q_mean'].values)
-    assert q.shape == qm.shape == (4, 2, 48, 48)                       # IC + 3 daily snapshots
-    np.testing.assert_allclose(q[0], q_init.astype('float32'), rtol=1e-6)
-    np.testing.assert_allclose(qm[0], q[0], rtol=1e-6)                 # identical initial condition
+    assert out['q'].dims == ('time', 'lev', 'y', 'x') and q.shape == qm.shape == (ndays + 1, 2, N, N)
+    q_init = operators_ref.Operator2(q_hires, N)
+    np.testing.assert_allclose(q[0], q_init.astype('float32'), rtol=0, atol=1e-6 * np.abs(q_init).max())
+    np.testing.assert_array_equal(qm[0], q[0])                         # identical initial condition
     assert np.abs(qm[-1] - q[-1]).max() > 0                            # members diverged through the noise
+    ora = load_generator('vae')
+    finals, psi0 = [], None
+    for b in range(n_ens):
+        m = qg_ref.QGModelRef(nx=N, dt=14400., tmax=86400. * ndays)
+        m.sampling_type = 'AR1'
+        m.noise_sampler = samplers_ref.make_sampler('AR1', 10)
+        m.q_parameterization = gen_ref.ParameterizationRef(ora, rng=_PhiloxRng(seed, b))
+        m.set_q(q_init)
+        m._invert()
+        m.run()
+        finals.append(m.q.copy())
+        if b == 0:
+            psi0 = m.ifft(m.ph)            # from the last inversion, as pyqg's to_dataset exports it
+    sc = np.abs(finals[0]).max(axis=(1, 2), keepdims=True)
+    # float32 generator differences accumulate over 12 steps; snapshots are stored as float32
+    assert (np.abs(q[-1] - finals[0]) / sc).max() < 2e-5
+    assert (np.abs(qm[-1] - np.mean(finals, axis=0)) / sc).max() < 2e-5
+    psc = np.abs(psi0).max(axis=(1, 2), keepdims=True)
+    assert (np.abs(np.asarray(out['psi'].values)[-1] - psi0) / psc).max() < 2e-5
+
+
+def test_deterministic_sampling_matches_oracle(tmp_path):
+    """sampling='deterministic' (parameterization.py:27-28): predict_mean_snapshot(M) with the pinned
+    Philox stream against the oracle's mean over the same M realisations (cgan_regression.py:164-171),
+    and one online step driven through it."""
+    from pyqg_generative_amd.models import CGANRegression, MeanVarModel
+    from pyqg_generative_amd.tools.stochastic_pyqg import stochastic_QGModel
+    model = CGANRegression(folder=_model_folder(tmp_path, 'gan'))
+    ora = load_generator('gan')
+    g = golden('generator.npz')
+    N, M, seed = 64, 12, 21
+    q = g['gan_64_q'].astype('float64')
+
+    class Mq:
+        pass
+    mq = Mq()
+    mq.q = q
+    mean = model.predict_mean_snapshot(mq, M=M, seed=seed)
+    ys = []
+    for j in range(M):
+        z, _ = samplers_ref.philox_normal(seed, j, 0, 2 * N * N)
+        ys.append(ora.predict_snapshot(q, z.reshape(1, 2, N, N)))
+    ref = np.mean(ys, axis=0)
+    sc = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    assert mean.shape == (2, N, N) and (np.abs(mean - ref) / sc).max() < 2e-5
+    # the unseeded variant follows numpy's global stream like the reference
+    np.random.seed(4)
+    m1 = model.predict_mean_snapshot(mq, M=3)
+    np.random.seed(4)
+    z = np.random.randn(3, 2, N, N).astype('float32')
+    ref1 = np.mean([ora.predict_snapshot(q, z[j:j + 1]) for j in range(3)], axis=0)
+    assert (np.abs(m1 - ref1) / sc).max() < 2e-5
+    # online: a deterministic-sampling model calls the plugin on the host every step (GZ: mean net only)
+    gz = MeanVarModel(folder=_model_folder(tmp_path, 'gz'))
+    ogz = load_generator('gz')
+    m = stochastic_QGModel(dict(nx=N, dt=14400., tmax=14400. * 3, parameterization=gz, log_level=0), 'deterministic')
+    r = qg_ref.QGModelRef(nx=N, dt=14400., tmax=14400. * 3)
+    r.sampling_type = 'deterministic'
+    r.q_parameterization = gen_ref.ParameterizationRef(ogz)
+    m.q = q
+    r.set_q(q)
+    m.run()
+    r.run()
+    assert np.abs(m.qh - r.qh).max() < 2e-6 * np.abs(r.qh).max()
+    m.close()
+
+
+def test_device_model_dataset_feeds_the_online_metrics(tmp_path):
+    """to_dataset() of the device model (with its time-averaged diagnostics) through the reference's
+    snapshot flow and metric accesses, against the same flow on an oracle run: 2 members ('run' axis)."""
+    from pyqg_generative_amd.qgmodel import QGModel
+    from pyqg_generative_amd.tools import simulate, spectral_tools
+    from pyqg_generative_amd import xarray_output
+    from test_dataset_cpu import _online_metric_accesses
+    xr = simulate.dataset_backend()
+    N, dt, B = 48, 14400., 2
+    kw = dict(nx=N, dt=dt, tmax=dt * 24, tavestart=dt * 6, taveint=dt * 2, log_level=0)
+    m = QGModel(n_members=B, **kw)
+    simulate.set_initial_condition(m, seeds=[0, 1])
+    m.q = m.q * 30
+    parts = []
+    full = None
+    for _ in m.run_with_snapshots(tsnapint=dt * 8):
+        full = m.to_dataset()
+        parts.append(simulate.drop_vars(full))
+    assert full['qh'].dims == ('run', 'time', 'lev', 'l', 'k') and full['KEspec'].dims == ('run', 'time', 'lev', 'l', 'k')
+    assert full.attrs['pyqg:nx'] == N and full.attrs['pyqg:tc'] == 24
+    np.testing.assert_array_equal(np.asarray(full['k'].values), m.kk)
+    ds = simulate.concat_in_time(parts)
+    assert ds['q'].dims == ('run', 'time', 'lev', 'y', 'x') and ds['q'].shape == (B, 3, 2, N, N)
+    assert ds['KEspec'].dims == ('run', 'lev', 'l', 'k') and ds['APEgenspec'].dims == ('run', 'l', 'k')
+    # the oracle through the same host flow
+    runs = []
+    for b in range(B):
+        r = qg_ref.QGModelRef(**{**kw, 'tmax': dt * 24})
+        qg_ref.set_initial_condition(r, np.random.RandomState(b))
+        r.set_q(r.q * 30)
+        rparts = []
+        for _ in r.run_with_snapshots(tsnapint=dt * 8):
+            fields = dict(q=r.q, u=r.u, v=r.v, p=r.ifft(r.ph))
+            diags = {k: v for k, v in r.diag.items() if k in xarray_output.DIAGNOSTICS}
+            rparts.append(simulate.drop_vars(xarray_output.model_to_dataset(r, fields=fields, diagnostics=diags, xr=xr)))
+        runs.append(simulate.concat_in_time(rparts))
+    ref = xr.concat(runs, 'run')
+    for name in ('q', 'u', 'v', 'psi', 'KEspec', 'KEflux', 'APEflux', 'APEgenspec', 'KEfrictionspec'):
+        a, b_ = np.asarray(ds[name].values), np.asarray(ref[name].values)
+        assert a.shape == b_.shape, name
+        assert np.abs(a - b_).max() <= 2e-6 * np.abs(b_).max(), name       # float32 storage
+    diffs = _online_metric_accesses(xr, ds, ref)
+    for k, (diff, scale) in diffs.items():
+        assert abs(diff) <= 1e-5 * scale, k
+    # north_star's KE-spectrum metric: calc_ispec(m, 0.5 * ave_lev(KEspec, delta)) of the ensemble mean
+    from pyqg_generative_amd.tools.operators import ave_lev
+    kr, sp = spectral_tools.calc_ispec(m, 0.5 * ave_lev(ds['KEspec'].mean('run'), m.delta))
+    kr0, sp0 = spectral_tools.calc_ispec(m, 0.5 * ave_lev(ref['KEspec'].mean('run'), m.delta))
+    assert np.abs(sp - sp0).max() <= 2e-6 * np.abs(sp0).max()
+    m.close()
 
 
 def test_offline_monte_carlo_moments(tmp_path):
@@ -216,3 +352,23 @@ def test_offline_monte_carlo_moments(tmp_path):
     assert np.abs(sample[0] - ys[0]).max() < 5e-5 * sc
     assert np.abs(mean[0] - ys.mean(0)).max() < 5e-5 * sc
     assert np.abs(var[0] - ys.var(0, ddof=1)).max() < 2e-4 * ys.var(0, ddof=1).max()
+
+
+def test_bench_two_rank_rehearsal_over_gloo():
+    """The `torchrun ... bench.py --gpus N` launch path (sharded members, barrier-bracketed timing, max over
+    ranks, the ensemble-mean spectrum all-reduce at snapshot time) with two ranks sharing this box's one GPU
+    and gloo in place of RCCL."""
+    import subprocess, sys
+    root = os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0]
+    env = dict(os.environ, QGX_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', '29655', os.path.join(root, 'bench.py'),
+           '--gpus', '2', '--backend', 'gloo', '--steps', '260', '--warmup', '0', '--members', '4']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['total_members'] == 8 and out['scaling'] == 'weak'
+    assert out['healthy'] and out['value'] > 0 and out['config']['cadence']['snapshots_in_timed_region'] == 1
+    assert abs(out['value'] - 8 * 260 / (out['ms_per_step'] * 260e-3)) < 1e-6 * out['value']
+    assert out['roofline']['launches_timed'] == 260 and 0 < out['roofline']['frac'] < 1

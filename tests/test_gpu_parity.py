@@ -203,18 +203,30 @@ def test_philox_noise_matches_oracle_stream():
     assert abs(s.mean()) < 0.01 and abs(s.std() - 1) < 0.01 and abs((s ** 4).mean() - 3) < 0.1
 
 
-@pytest.mark.parametrize('kind,sampling,nd', [('gan', 'AR1', 1), ('vae', 'AR1', 3), ('gz', 'constant', 2),
-                                              ('gan', 'constant', 1)])
-def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd):
-    """configs[1] (B=1..2): full online step = sampler + generator + de-mean + spectral step,
-    with the white noise xi supplied externally so that both sides see identical draws."""
+JET = dict(dt=7200., rek=7e-8, delta=0.1, beta=1e-11)      # tools/parameters.py:26-27,37
+
+
+@pytest.mark.parametrize('kind,sampling,nd,N,B,nsteps,params', [
+    ('gan', 'AR1', 1, 64, 2, 5, dict(dt=14400.)),
+    ('vae', 'AR1', 3, 64, 2, 5, dict(dt=14400.)),
+    ('gz', 'constant', 2, 64, 2, 5, dict(dt=14400.)),
+    ('gan', 'constant', 1, 64, 2, 5, dict(dt=14400.)),
+    ('gan', 'constant', 1, 64, 1, 5, dict(dt=14400.)),      # BASELINE configs[1] exactly: one member
+    ('vae', 'constant', 1, 96, 32, 3, JET),                  # BASELINE configs[3]'s per-GPU shard
+    ('vae', 'AR1', 2, 96, 3, 4, JET),
+    ('gan', 'AR1', 1, 48, 2, 4, dict(dt=14400.)),           # the notebooks' resolution
+    ('vae', 'AR1', -1, 64, 2, 4, dict(dt=14400.)),          # nsteps < 0: the first draw is frozen (stochastic_pyqg.py:42-47)
+], ids=lambda v: str(v) if not isinstance(v, dict) else ('jet' if 'rek' in v else 'eddy'))
+def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd, N, B, nsteps, params):
+    """configs[1] (64x64 eddy + CGAN, B=1) and configs[3]'s shard (96x96 jet + CVAE, B=32): the full
+    online step = sampler + generator + de-mean + spectral step, with the white noise xi supplied
+    externally so that both sides see identical draws."""
     import pyqg_generative_amd._lib as L
-    N, B, nsteps = 64, 2, 5
     rs = np.random.RandomState(77)
     q0 = _eddy_like_q(rs, B, N)
     gen = _gpu_generator(kind)
     ora = load_generator(kind)
-    e = _engine(N, B, dt=14400.)
+    e = _engine(N, B, **params)
     e.set_q(q0)
     if kind == 'gz':
         xis = [rs.randn(B, 2, N, N) for _ in range(nsteps)]
@@ -230,7 +242,7 @@ def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd
 
             def randn(self, *shape):
                 return next(self.it).astype('float64').reshape(shape)
-        m = qg_ref.QGModelRef(nx=N, dt=14400.)
+        m = qg_ref.QGModelRef(nx=N, **params)
         m.sampling_type = sampling
         m.noise_sampler = samplers_ref.make_sampler(sampling, nd)
         m.q_parameterization = gen_ref.ParameterizationRef(ora, rng=_Rng(it))

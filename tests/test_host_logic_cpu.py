@@ -58,19 +58,27 @@ def test_scaler_json_roundtrip(tmp_path):
     np.testing.assert_array_equal(read_scaler_std(str(tmp_path / 'x_scale.json')), [2.0, 4.0])
 
 
-def test_xr_lite_snapshot_flow(tmp_path):
+def test_xr_lite_follows_xarray_semantics(tmp_path):
+    """the stand-in used when xarray is absent: the xarray behaviours the snapshot flow relies on"""
     from pyqg_generative_amd.tools import xr_lite as xr
     def snap(t):
         return xr.Dataset({'q': (('time', 'lev', 'y', 'x'), np.full((1, 2, 4, 4), t, np.float32)),
                            'KEspec': (('lev', 'l', 'k'), np.full((2, 4, 3), t))},
-                          coords={'time': xr.DataArray(np.array([t], np.float32), ['time'])})
+                          coords={'time': (('time',), np.array([t], np.float32)), 'k': (('k',), np.arange(3.))})
     ds = xr.concat([snap(1.), snap(2.), snap(3.)], dim='time')
-    assert ds['q'].shape == (3, 2, 4, 4) and ds['KEspec'].shape == (2, 4, 3)
-    assert ds['KEspec'].values[0, 0, 0] == 3.0            # spectral stats come from the last snapshot
+    # variables without the concat dimension are broadcast along it (xarray's data_vars='all')
+    assert ds['q'].shape == (3, 2, 4, 4) and ds['KEspec'].dims == ('time', 'lev', 'l', 'k')
+    assert ds['KEspec'].isel(time=-1).values[0, 0, 0] == 3.0
     np.testing.assert_array_equal(ds['time'].values, [1, 2, 3])
     assert ds.q.isel(time=-1).shape == (2, 4, 4)
+    assert list(ds.keys()) == ['q', 'KEspec'] and 'k' in ds.variables and 'k' not in ds.keys()
+    with pytest.raises(ValueError):
+        ds['k'].isel(time=0)                               # missing dimensions raise, as in xarray
     ds2 = ds.rename({'q': 'psi'}).drop_vars('KEspec').astype('float32')
     assert 'psi' in ds2 and 'KEspec' not in ds2 and 'q' in ds
+    stacked = xr.concat([ds, ds], 'run')                   # a new dimension goes first
+    assert stacked['q'].dims == ('run', 'time', 'lev', 'y', 'x')
+    assert (stacked['q'].mean('run') - ds['q']).values.max() == 0
     ds.to_netcdf(str(tmp_path / 'a.nc'))
     from scipy.io import netcdf_file
     with netcdf_file(str(tmp_path / 'a.nc'), 'r', mmap=False) as f:
