@@ -95,6 +95,10 @@ def _load():
             f'{LIB_PATH} is missing: the HIP extension is not built. Run '
             '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C '
             'pyqg_generative_amd/csrc`). There is no CPU fallback.')
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so) with the same soname as
+    # /opt/rocm's, and this library links against that soname: whichever is loaded first serves both.
+    # Load torch's first — torch finds no GPU when it is handed the other runtime.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the library lacks a declared symbol

@@ -1256,6 +1256,7 @@ static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const v
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[NS - 1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[NS - 1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = N; a.R = R;
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (N / R);
@@ -1299,6 +1300,7 @@ static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, cons
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = NN; a.R = R;
     a.prio_alt = KS == 5 ? g->opt_prio_alt : 0;      // measured: -2 % on the 5x5 layer, nothing on the 3x3 layers
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
@@ -1338,6 +1340,7 @@ static int launch_convh2_part_n(qgx_generator *g, int layer, const LayerHost &L,
     ConvHArgs a = {};
     a.in = in; a.out = g->part; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = NN; a.R = R; a.npix_total = npix;
     const int total_tiles = B * (NN / R);
     constexpr bool TWO = lds * 2 <= 160 * 1024 && MT == 2;
@@ -1347,7 +1350,7 @@ static int launch_convh2_part_n(qgx_generator *g, int layer, const LayerHost &L,
     const size_t n = npix * (COUT / 8);
     hipLaunchKernelGGL((k_convh_reduce<COUT, OUTF32>), dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
                        (const float *)g->part, nsplit, npix, (const float *)L.bias, (const float *)L.scale, (const float *)L.shift,
-                       a.unscale, a.ascale, out);
+                       a.unscale, a.ascale, out, a.range, a.range_bit);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
@@ -1380,6 +1383,7 @@ static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, con
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = NN; a.R = R;
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (NN / R) * (NN / TW);
@@ -1404,6 +1408,7 @@ static int launch_convh2_w8_3x3(qgx_generator *g, int layer, const LayerHost &L,
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = NN; a.R = R;
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (NN / R);
@@ -1461,6 +1466,7 @@ static int launch_convh_res(qgx_generator *g, int layer, const LayerHost &L, con
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = N; a.R = R;
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (N / R);
@@ -1510,6 +1516,7 @@ static int launch_convh3(qgx_generator *g, int layer, const LayerHost &L, const 
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh16; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = N; a.R = R;
     const int total_tiles = B * (N / R);
     int grid = 256;
@@ -1534,6 +1541,7 @@ static int launch_convh4_n(qgx_generator *g, int layer, const LayerHost &L, cons
     ConvHArgs a = {};
     a.in = in; a.out = out; a.w = L.wh[1]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = NN; a.R = R;
     const int total_tiles = B * (NN / R);
     int grid = 256;
@@ -1570,6 +1578,7 @@ static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, 
     a.biasA = LA.bias; a.scaleA = LA.scale; a.shiftA = LA.shift;
     a.biasB = LB.bias; a.scaleB = LB.scale; a.shiftB = LB.shift;
     a.unscaleA = LA.wh_unscale[1] / g->opt_ascale; a.unscaleB = LB.wh_unscale[1] / g->opt_ascale; a.ascale = g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layerA;
     a.n_out = n_out;
     a.stamps = layerA == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (N / R);
@@ -1606,6 +1615,7 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
     a.stamps = g->stamp_layer == 0 ? g->stamps : nullptr;
     a.in = in; a.out = out; a.w = L.whf; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.whf_unscale; a.ascale = g->opt_ascale; a.N = N; a.R = R;
+    a.range = g->range_dev; a.range_bit = 1u;
     const int total_tiles = B * (N / R);
     const int wgs = lds * 2 <= 160 * 1024 ? 2 : 1;
     int grid = 256 * wgs;

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void k_convh3(ConvHArgs a, int total_tiles) {
                                     const _Float16 xh = (_Float16)x;
                                     hi[e] = (float)xh;
                                     lo[e] = x - hi[e];
+                                    range_guard(fabsf(x), a.range, a.range_bit);
                                 }
                                 hw[ab][0] = pack_h2(hi[0], hi[1]); hw[ab][1] = pack_h2(hi[2], hi[3]);
                                 lw[ab][0] = pack_h2(lo[0], lo[1]); lw[ab][1] = pack_h2(lo[2], lo[3]);

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NW * 64) void k_convh4(ConvHArgs a, int total_tiles
                         char *pix = ob + (size_t)((wave + NW * mt) * 32 + li) * OPIXB;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            store_tile_t<2, false>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                            store_tile_t<2, false>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
                     }
                 }
             }

@@ -43,6 +43,8 @@ struct ConvHArgs {
     int N, R;
     size_t npix_total;     // split-K: B*N*N, the stride of one partial-sum plane
     int prio_alt;          // k_convh2: alternate the wave priority of the two co-resident workgroups per tile
+    unsigned *range;       // f16x3 range guard: sticky flag word of the generator (bit = layer), see range_guard()
+    unsigned range_bit;
     unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only: s_memtime trace, 64 slots per workgroup
 };
 
@@ -74,6 +76,14 @@ struct ConvHArgs {
         if (it_ < (NUNITS)) reinterpret_cast<f32x4 *>(DST)[it_] = V[u];                                     \
     }
 
+// f16x3 range guard.  A stored activation whose hi part leaves the f16 range (|x| > 65504) becomes inf and
+// the next layer turns it into inf / NaN — or, behind a ReLU, into an innocent-looking zero.  Every epilogue
+// that stores 16-bit activations passes the largest magnitude it stored through here; an overflow raises a
+// sticky per-layer bit that qgx_generator_range_read reports (the facade re-runs in exact f32 / aborts).
+__device__ __forceinline__ void range_guard(float mx, unsigned *range, unsigned bit) {
+    if (mx > 65504.f) atomicOr(range, bit);
+}
+
 __device__ __forceinline__ unsigned pack_h2(float a, float b) {
     h2 v = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, v);
@@ -83,7 +93,8 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
 // lane (li, h) owns pixel li; register r holds output channel cb + (r & 3) + 8 (r >> 2) + 4 h.
 template <int NS, bool OUTF32>
 __device__ __forceinline__ void store_tile_t(const f32x16 &acc, int cb, int h, char *pix, const float *bias,
-                                             const float *scale, const float *shift, float unscale, float ascale) {
+                                             const float *scale, const float *shift, float unscale, float ascale,
+                                             unsigned *range, unsigned range_bit) {
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -101,6 +112,10 @@ __device__ __forceinline__ void store_tile_t(const f32x16 &acc, int cb, int h, c
             *reinterpret_cast<f32x4 *>(pix + (size_t)(cb + 8 * q + 4 * h) * 4) = o;
         }
     } else {
+        float mx = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(v[e]));
+        range_guard(mx * ascale, range, range_bit);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             float hi[8], lo[8];
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles)
                         char *pix = ob + (size_t)(tile * 32 + li) * OPIXB;
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            store_tile_t<NS, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                            store_tile_t<NS, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
                     }
                 }
             }
@@ -671,7 +686,7 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
                             char *pix = ob + (size_t)((p / TW) * N + p % TW) * OPIXB;
 #pragma unroll
                             for (int nt = 0; nt < NT; ++nt)
-                                store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                                store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
                         }
                     }
                 }
@@ -690,7 +705,8 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
 // and octet of channels, output in the packed hi/lo layout (or NHWC f32)
 template <int COUT, bool OUTF32>
 __global__ void k_convh_reduce(const float *partial, int nsplit, size_t npix_total, const float *bias, const float *scale,
-                               const float *shift, float unscale, float ascale, void *out) {
+                               const float *shift, float unscale, float ascale, void *out, unsigned *range,
+                               unsigned range_bit) {
     const size_t n = npix_total * (COUT / 8);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int g = (int)(i % (COUT / 8));
@@ -715,6 +731,10 @@ __global__ void k_convh_reduce(const float *partial, int nsplit, size_t npix_tot
             *reinterpret_cast<f32x4 *>(o + 4) = o1;
         } else {
             unsigned hw[4], lw[4];
+            float mx = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(x[e]));
+            range_guard(mx * ascale, range, range_bit);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a0 = x[2 * e] * ascale, a1 = x[2 * e + 1] * ascale;
@@ -745,6 +765,8 @@ struct ConvHFirstArgs {
     float unscale, ascale;
     int N, R;
     unsigned long long *stamps;   // diagnostic builds only
+    unsigned *range;       // range guard flag word, bit of this layer (see range_guard)
+    unsigned range_bit;
 };
 
 template <int NIN, int MT, int PPT, int NW = 4>
@@ -899,7 +921,7 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
                 char *pix = ob + (size_t)(tile * 32 + li) * (COUT * 4);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
-                    store_tile_t<2, false>(acc[mt][nt], half * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                    store_tile_t<2, false>(acc[mt][nt], half * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
             }
             QGX_STAMP()
         }
@@ -1069,7 +1091,7 @@ __global__ __launch_bounds__(512) void k_convh_res(ConvHArgs a, int total_tiles)
                     char *pix = ob + (size_t)(tile * 32 + li) * OPIXB;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale);
+                        store_tile_t<2, OUTF32>(acc[mt][nt], nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
                 }
             }
             QGX_STAMP()

@@ -27,6 +27,8 @@ struct ConvPairArgs {
     const float *biasA, *scaleA, *shiftA, *biasB, *scaleB, *shiftB;
     float unscaleA, unscaleB, ascale;
     int n_out;             // LAST: number of real output channels (<= 2)
+    unsigned *range;       // range guard flag word; bit_a: the intermediate in LDS, bit_a << 1: layer B's output
+    unsigned range_bit;
     unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only
 };
 
@@ -233,6 +235,12 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
                         for (int e = 0; e < 4; ++e)
                             v[4 * q + e] = (fmaxf(accA[mt][4 * q + e] * a.unscaleA + bi[e], 0.f) * sc[e] + sh[e]) * a.ascale;
                     }
+                    {
+                        float mx = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(v[e]));
+                        range_guard(mx, a.range, a.range_bit);
+                    }
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
                         float hi[8], lo[8];
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
                 } else {
                     constexpr int OPIXB = 32 * 4;
                     char *pix = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N + p) * OPIXB;
-                    store_tile_t<2, BOUTF32>(accB[mt], 0, h, pix, epB, epB + 32, epB + 64, a.unscaleB, BOUTF32 ? 1.f : a.ascale);
+                    store_tile_t<2, BOUTF32>(accB[mt], 0, h, pix, epB, epB + 32, epB + 64, a.unscaleB, BOUTF32 ? 1.f : a.ascale, a.range, a.range_bit << 1);
                 }
             }
         }
