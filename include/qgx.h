@@ -212,6 +212,17 @@ int qgx_moments_accumulate(const float *y_dev, double *sum_dev, double *sumsq_de
  * channels staged per pass of k_conv), "v3" (-1 auto | 0 | 1 | 2: LDS-operand kernel k_conv3),
  * "last_valu" (0|1), "first_split" (1|2|4 output-channel slices of the first layer). */
 int qgx_generator_set_option(qgx_generator *g, const char *name, int value);
+/* f16x3 range guard (no reference counterpart: the reference evaluates its nets in plain float32).  The default
+ * generator arithmetic carries float32 operands as f16 hi/lo pairs, which is float32-class only inside a value window;
+ * qgx_generator_create calibrates each net (exact-f32 evaluation of calibration inputs) and picks the activation
+ * pre-scale — or makes the exact-f32 kernels the default when the window cannot be met — and every kernel that stores
+ * 16-bit activations raises a sticky flag when a value leaves the f16 range.
+ * _range_read: synchronises `stream`, returns and clears the flags (bit l = layer l+1 overflowed, bit 31 = non-finite
+ * forcing) and the largest |network input| seen since the last read (inputs beyond 65504, or NaN = inf, overflow too).
+ * _info: what calibration decided (precision 0 | 3, log2 of the activation pre-scale, fold 0 | 1) and the calibration
+ * maxima per layer (10 floats: [0..6] stored activations, [8] layer 1 before its BatchNorm). */
+int qgx_generator_range_read(qgx_generator *g, unsigned *flags, float *input_absmax, void *stream);
+int qgx_generator_info(const qgx_generator *g, int *precision, int *ascale_log2, int *fold, float *layer_absmax);
 int qgx_generator_profile(qgx_generator *g, int layer);
 int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches);
 

@@ -37,6 +37,7 @@ struct ConvArgs {
     int N, R, cout_real;
     size_t npix_total;     // B*N*N (stride of one split-K partial plane)
     float ascale;          // OUTH: power-of-two pre-scale of the stored 16-bit activations
+    unsigned *range;       // OUTH: f16x3 range guard flag word (conv_half.hpp::range_guard)
 };
 
 extern __shared__ __attribute__((aligned(16))) char conv_smem[];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
                         ((size_t)b * N * N + (size_t)y0 * N + tile * 32 + li) * (COUT * 2 * OUTH);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                store_tile_t<OUTH, false>(acc[mt][nt], (nt0 + nt) * 32, h, pix, a.bias, a.scale, a.shift, 1.0f, a.ascale);
+                store_tile_t<OUTH, false>(acc[mt][nt], (nt0 + nt) * 32, h, pix, a.bias, a.scale, a.shift, 1.0f, a.ascale, a.range, 1u);
             continue;
         }
 #pragma unroll
@@ -613,47 +614,75 @@ __global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
 
 // ---- small pointwise kernels around the CNN ---------------------------------------------
 // X = [float(q)/x_std, z]  (cgan_regression.py:158 + generate :133-137)
-__global__ void k_prep_input(const double *q, const float *z, float *X, int n_in, int npix, float xs0, float xs1) {
+// largest |x| of the network input, for the f16x3 range guard: a NaN counts as infinity; non-negative floats
+// order like their bit patterns, so one atomicMax on the bits per wave keeps the running maximum
+__device__ __forceinline__ void input_absmax(float m, unsigned *range) {
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(range + 1, __float_as_uint(m));
+}
+__device__ __forceinline__ float abs_or_inf(float x) { return x != x ? __uint_as_float(0x7f800000u) : fabsf(x); }
+
+__global__ void k_prep_input(const double *q, const float *z, float *X, int n_in, int npix, float xs0, float xs1,
+                             unsigned *range) {
     const int b = blockIdx.y;
+    float m = 0.f;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         const size_t qo = (size_t)b * 2 * npix + i;
         float *x = X + (size_t)b * n_in * npix + i;
-        x[0] = (float)q[qo] / xs0;
-        x[npix] = (float)q[qo + npix] / xs1;
+        const float x0 = (float)q[qo] / xs0, x1 = (float)q[qo + npix] / xs1;
+        x[0] = x0;
+        x[npix] = x1;
+        m = fmaxf(m, fmaxf(abs_or_inf(x0), abs_or_inf(x1)));
         if (n_in == 4) {
-            x[2 * (size_t)npix] = z[qo];
-            x[3 * (size_t)npix] = z[qo + npix];
+            const float z0 = z[qo], z1 = z[qo + npix];
+            x[2 * (size_t)npix] = z0;
+            x[3 * (size_t)npix] = z1;
+            m = fmaxf(m, fmaxf(abs_or_inf(z0), abs_or_inf(z1)));
         }
     }
+    input_absmax(m, range);
+}
+
+__global__ void k_absmax(const float *x, size_t n, unsigned *range) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, abs_or_inf(x[i]));
+    input_absmax(m, range);
 }
 
 // Fused sampler update + input assembly of one online step (GAN / VAE):
 //   z <- a z + b xi  (float; xi from Philox or the external draw), X = [float(q)/x_std, z]
 // One thread per quad of 4 consecutive elements of the (2,N,N) member field.
 __global__ void k_prep_noise(const double *q, float *z, const float *xi_ext, float *X, int npix, float xs0,
-                             float xs1, uint64_t seed, uint64_t member_offset, uint64_t step, float a, float b) {
+                             float xs1, uint64_t seed, uint64_t member_offset, uint64_t step, float a, float b,
+                             unsigned *range) {
     const int member = blockIdx.y;
     const int quads = 2 * npix / 4;
     const int quad = blockIdx.x * blockDim.x + threadIdx.x;
-    if (quad >= quads) return;
-    const size_t o = (size_t)member * 2 * npix + 4 * (size_t)quad;
-    float x[4];
-    if (xi_ext) {
+    float m = 0.f;
+    if (quad < quads) {
+        const size_t o = (size_t)member * 2 * npix + 4 * (size_t)quad;
+        float x[4];
+        if (xi_ext) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = xi_ext[o + e];
-    } else {
-        philox_normal4(seed, member_offset + member, step, (uint32_t)quad, x);
-    }
-    float *Xm = X + (size_t)member * 4 * npix;
-    const int i = 4 * quad;                          // flat index in (2, npix); npix % 4 == 0
-    const float xs = i < npix ? xs0 : xs1;
+            for (int e = 0; e < 4; ++e) x[e] = xi_ext[o + e];
+        } else {
+            philox_normal4(seed, member_offset + member, step, (uint32_t)quad, x);
+        }
+        float *Xm = X + (size_t)member * 4 * npix;
+        const int i = 4 * quad;                          // flat index in (2, npix); npix % 4 == 0
+        const float xs = i < npix ? xs0 : xs1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float zn = a == 0.f ? b * x[e] : a * z[o + e] + b * x[e];
-        z[o + e] = zn;
-        Xm[2 * (size_t)npix + i + e] = zn;
-        Xm[i + e] = (float)q[o + e] / xs;
+        for (int e = 0; e < 4; ++e) {
+            const float zn = a == 0.f ? b * x[e] : a * z[o + e] + b * x[e];
+            z[o + e] = zn;
+            Xm[2 * (size_t)npix + i + e] = zn;
+            const float xq = (float)q[o + e] / xs;
+            Xm[i + e] = xq;
+            m = fmaxf(m, fmaxf(abs_or_inf(zn), abs_or_inf(xq)));
+        }
     }
+    input_absmax(m, range);
 }
 
 // Fused output scaling + per-layer de-mean: one workgroup per (member, layer).
@@ -662,7 +691,7 @@ __global__ void k_prep_noise(const double *q, float *z, const float *xi_ext, flo
 //   then S -= mean_{y,x} S                                 (parameterization.py:25)
 template <bool GZ>
 __global__ __launch_bounds__(1024) void k_finish(const float *y0, const float *y1, const double *z, double *S, int npix, float ys0,
-                                                 float ys1, int demean) {
+                                                 float ys1, int demean, unsigned *range) {
     __shared__ double sm[16];
     __shared__ double mean_s;
     const size_t o = (size_t)blockIdx.x * npix;
@@ -706,13 +735,22 @@ __global__ __launch_bounds__(1024) void k_finish(const float *y0, const float *y
         mu = mean_s;
     }
     if (cached) {
+        bool bad = false;
 #pragma unroll
         for (int u = 0; u < KEEP; ++u) {
             const int i = u * blockDim.x + threadIdx.x;
             if (i < npix) S[o + i] = keep[u] - mu;
+            bad |= !(fabs(keep[u]) <= 1.79e308);
         }
+        if (bad) atomicOr(range, 0x80000000u);      // a non-finite forcing never reaches the model unnoticed
     } else {
-        for (int i = threadIdx.x; i < npix; i += blockDim.x) S[o + i] = value(i) - mu;
+        bool bad = false;
+        for (int i = threadIdx.x; i < npix; i += blockDim.x) {
+            const double val = value(i);
+            S[o + i] = val - mu;
+            bad |= !(fabs(val) <= 1.79e308);
+        }
+        if (bad) atomicOr(range, 0x80000000u);
     }
 }
 
@@ -781,7 +819,13 @@ struct qgx_generator {
     int opt_first_h = 1;           // f16x3 path: first layer on the 16-bit cores too (0: exact-f32 MFMA first layer)
     int opt_precision = 3;         // 0 = exact f32 MFMA, 1 = f16 MFMA, 3 = f16x3 split (f32-class accuracy; default
                                    // wherever the ensemble fills the 8-wave tiles, see half_path_ok)
-    float opt_ascale = 1.f;        // power-of-two pre-scale of stored 16-bit activations
+    float opt_ascale = 1.f;        // power-of-two pre-scale of stored 16-bit activations (chosen by calibrate())
+    // f16x3 range guard (conv_half.hpp::range_guard): [0] sticky flags — bit l: layer l stored a value beyond the f16
+    // range, bit 31: non-finite forcing; [1] bits of the largest |network input| seen
+    unsigned *range_dev = nullptr;
+    unsigned *calib_dev = nullptr; // calibration only: per-layer max |activation| of the exact-f32 evaluation
+    float calib_max[10] = {0};     // [0..6] stored (post-BatchNorm) activations, [8] layer 1 before its BatchNorm
+    int auto_precision = 3, auto_fold = 1, auto_ascale_log2 = 0;   // what calibrate() decided
     int prof_layer = -1;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
     size_t prof_used = 0;
@@ -1022,6 +1066,7 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
     ConvArgs a = {};
     a.in = in; a.out = out; a.w = (!PLANAR_IN && CC == 32) ? L.w32 : L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.N = N; a.R = R; a.cout_real = cout_real; a.npix_total = (size_t)B * N * N; a.ascale = g->opt_ascale;
+    a.range = g->range_dev;
     constexpr int STRIDE = PLANAR_IN ? CIN : CC + 4;
     const size_t lds = (size_t)(R + KS - 1) * N * STRIDE * sizeof(float);
     QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
@@ -1746,15 +1791,115 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
             : g->opt_first_split == 4 ? launch_conv<2, 128, 5, 2, true, false, 4>(g, 0, net.L[0], x, A, B, N, 128, st)
                                       : launch_conv<2, 128, 5, 2, true, false, 1>(g, 0, net.L[0], x, A, B, N, 128, st);
     if (rc) return rc;
+    // calibration runs record the largest stored activation of every layer (k_absmax keeps a running maximum
+    // in calib_dev[2 * layer + 1]: it updates word [1] of the pair it is given)
+    auto rec = [&](int layer, const float *buf, int ch) {
+        if (g->calib_dev)
+            hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, buf, (size_t)B * N * N * ch, g->calib_dev + 2 * layer);
+    };
+    rec(0, A, 128);
     if ((rc = conv_hidden<128, 64, 5>(g, 1, net.L[1], A, Bb, B, N, st))) return rc;
+    rec(1, Bb, 64);
     if ((rc = conv_hidden<64, 32, 3>(g, 2, net.L[2], Bb, A, B, N, st))) return rc;
+    rec(2, A, 32);
     if ((rc = conv_hidden<32, 32, 3>(g, 3, net.L[3], A, Bb, B, N, st))) return rc;
+    rec(3, Bb, 32);
     if ((rc = conv_hidden<32, 32, 3>(g, 4, net.L[4], Bb, A, B, N, st))) return rc;
+    rec(4, A, 32);
     if ((rc = conv_hidden<32, 32, 3>(g, 5, net.L[5], A, Bb, B, N, st))) return rc;
+    rec(5, Bb, 32);
     if ((rc = conv_hidden<32, 32, 3>(g, 6, net.L[6], Bb, A, B, N, st))) return rc;
+    rec(6, A, 32);
     if (g->opt_last_valu) rc = launch_conv_last(g, net.L[7], A, y, B, N, net.n_out, st);
     else rc = launch_conv<32, 2, 3, 16, false, true>(g, 7, net.L[7], A, y, B, N, net.n_out, st);
     if (rc) return rc;
+    return QGX_OK;
+}
+
+
+// ---- f16x3 range calibration (run once by qgx_generator_create) ------------------------------------------------
+// The f16x3 arithmetic stores every activation x as hi = f16(s x), lo = f16(s x - hi) with ONE power-of-two scale s
+// for the whole net.  It is float32-class only while the stored values stay inside a window: above 65504 the hi part
+// overflows; below 2^-2 (relative to a layer's largest value) the lo part is subnormal and the pair no longer carries
+// 22 bits against that layer's scale.  Nothing about a user-trained net guarantees that, so the nets are evaluated
+// here once in EXACT f32 on calibration inputs (unit-variance white noise, smooth large-scale fields of amplitude 2-3,
+// constants: what ChannelwiseScaler-normalised PV and N(0,1) latent noise look like) and the largest stored
+// activation of every layer decides:
+//   * s = the power of two that puts the largest layer maximum at <= 2^10 (64x headroom below the f16 overflow for
+//     inputs hotter than the calibration set; the run-time guard range_guard() catches what still escapes),
+//     s = 1 whenever that already holds (the shipped nets);
+//   * "fold" (layer 1 stores its pre-BatchNorm ReLU output) only if that tensor fits the same window;
+//   * if the layer maxima span more than the window (2^12), f16x3 cannot be float32-class for this net:
+//     precision 0 (the exact-f32 MFMA kernels) becomes the default.
+static int calibrate(qgx_generator *g) {
+    QGX_HIP(hipMalloc((void **)&g->range_dev, 2 * sizeof(unsigned)));
+    QGX_HIP(hipMemset(g->range_dev, 0, 2 * sizeof(unsigned)));
+    const int N = 32, B = 8, npix = N * N;
+    int rc = reserve(g, B, N);
+    if (rc) return rc;
+    unsigned *cd = nullptr;
+    QGX_HIP(hipMalloc((void **)&cd, 20 * sizeof(unsigned)));
+    QGX_HIP(hipMemset(cd, 0, 20 * sizeof(unsigned)));
+    const int saved_precision = g->opt_precision;
+    g->opt_precision = 0;
+    for (int n = 0; n < g->n_nets && !rc; ++n) {
+        const NetHost &net = g->nets[n];
+        std::vector<float> x((size_t)B * net.n_in * npix);
+        uint32_t lcg = 12345u + 977u * n;
+        auto uni = [&]() { lcg = lcg * 1664525u + 1013904223u; return ((lcg >> 8) + 0.5f) * (1.0f / 16777216.0f); };
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < net.n_in; ++c)
+                for (int y = 0; y < N; ++y)
+                    for (int xx = 0; xx < N; ++xx) {
+                        float v;
+                        const float white = sqrtf(-2.f * logf(uni())) * cosf(6.2831853f * uni());
+                        if (b < 4) v = white * (b == 3 ? 2.f : 1.f);                      // white noise, one member hotter
+                        else if (b < 6) v = 2.f * sinf(6.2831853f * (y * (c + 1) + xx * (b - 3)) / N)
+                                            + cosf(6.2831853f * 2 * xx / N) + 0.3f * white;   // smooth, amplitude ~3
+                        else v = (b == 6 ? 3.f : -3.f) * ((c & 1) ? -1.f : 1.f);         // constants
+                        x[(((size_t)b * net.n_in + c) * N + y) * N + xx] = v;
+                    }
+        QGX_HIP(hipMemcpy(g->X, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice));
+        g->calib_dev = cd;
+        rc = cnn_forward(g, net, g->X, g->Y0, B, N, nullptr);
+        g->calib_dev = nullptr;
+        if (rc) break;
+        // layer 1 with an identity BatchNorm = what the folded f16x3 variant stores
+        LayerHost L0 = net.L[0];
+        L0.scale = L0.ones; L0.shift = L0.zeros;
+        rc = net.n_in == 4 ? launch_conv<4, 128, 5, 4, true, false, 2>(g, 0, L0, g->X, g->actA, B, N, 128, nullptr)
+                           : launch_conv<2, 128, 5, 2, true, false, 2>(g, 0, L0, g->X, g->actA, B, N, 128, nullptr);
+        if (rc) break;
+        hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, nullptr, (const float *)g->actA, (size_t)B * npix * 128, cd + 16);
+    }
+    g->opt_precision = saved_precision;
+    unsigned h[20];
+    if (!rc) {
+        if (hipMemcpy(h, cd, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) rc = QGX_ERR_HIP;
+    }
+    (void)hipFree(cd);
+    if (rc) return rc;
+    for (int l = 0; l < 10; ++l) memcpy(&g->calib_max[l], &h[2 * l + 1], sizeof(float));
+    auto window = [&](bool with_fold, float &lo, float &hi) {
+        lo = INFINITY; hi = 0.f;
+        for (int l = with_fold ? 1 : 0; l < 7; ++l)
+            if (g->calib_max[l] > 0.f) { lo = fminf(lo, g->calib_max[l]); hi = fmaxf(hi, g->calib_max[l]); }
+        if (with_fold && g->calib_max[8] > 0.f) { lo = fminf(lo, g->calib_max[8]); hi = fmaxf(hi, g->calib_max[8]); }
+    };
+    const float TOP = 1024.f, BOT = 0.25f;                 // window of s * (layer maximum)
+    float lo, hi;
+    int fold = 1;
+    window(true, lo, hi);
+    if (!(hi > 0.f) || !std::isfinite(hi) || hi / lo > TOP / BOT) { fold = 0; window(false, lo, hi); }
+    int precision = 3, e = 0;
+    if (!(hi > 0.f) || !std::isfinite(hi) || hi / lo > TOP / BOT) precision = 0;
+    else if (hi > TOP || lo < BOT) {
+        int eh = 0;
+        (void)frexpf(hi, &eh);                             // hi = m 2^eh, m in [0.5, 1): hi * 2^(10 - eh) in [512, 1024)
+        e = 10 - eh;
+    }
+    g->auto_precision = precision; g->auto_fold = fold; g->auto_ascale_log2 = e;
+    g->opt_precision = precision; g->opt_fold = fold; g->opt_ascale = ldexpf(1.f, e);
     return QGX_OK;
 }
 
@@ -1771,23 +1916,23 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
     if (g->kind == QGX_GEN_GZ) {
         if (nu && (rc = noise_update(const_cast<void *>(z), nu->xi_ext, true, B, 2 * npix, nu->seed, nu->member_offset,
                                      nu->step, nu->a, nu->b, st))) return rc;
-        hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)nullptr, g->X, 2, npix, g->x_std[0], g->x_std[1]);
+        hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)nullptr, g->X, 2, npix, g->x_std[0], g->x_std[1], g->range_dev);
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
         if ((rc = cnn_forward(g, g->nets[1], g->X, g->Y1, B, N, st))) return rc;
         hipLaunchKernelGGL(k_finish<true>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)g->Y1,
-                           (const double *)z, S, npix, g->y_std[0], g->y_std[1], demean);
+                           (const double *)z, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
     } else {
         if (nu) {
             dim3 qg((2 * npix / 4 + 255) / 256, B);
             hipLaunchKernelGGL(k_prep_noise, qg, pb, 0, st, q, (float *)const_cast<void *>(z), (const float *)nu->xi_ext,
                                g->X, npix, g->x_std[0], g->x_std[1], nu->seed, nu->member_offset, nu->step,
-                               (float)nu->a, (float)nu->b);
+                               (float)nu->a, (float)nu->b, g->range_dev);
         } else {
-            hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)z, g->X, 4, npix, g->x_std[0], g->x_std[1]);
+            hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)z, g->X, 4, npix, g->x_std[0], g->x_std[1], g->range_dev);
         }
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
         hipLaunchKernelGGL(k_finish<false>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)nullptr,
-                           (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean);
+                           (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
     }
     QGX_HIP(hipGetLastError());
     return QGX_OK;
@@ -1826,7 +1971,31 @@ extern "C" int qgx_generator_create(int kind, const qgx_cnn_weights *nets, int n
             if (rc) { qgx_generator_destroy(g); return rc; }
         }
     }
+    {
+        int rc = calibrate(g);
+        if (rc) { qgx_generator_destroy(g); return rc; }
+    }
     *out = g;
+    return QGX_OK;
+}
+
+extern "C" int qgx_generator_range_read(qgx_generator *g, unsigned *flags, float *input_absmax, void *stream) {
+    QGX_REQUIRE(g && flags && input_absmax, "qgx_generator_range_read: null argument");
+    unsigned h[2] = {0, 0};
+    QGX_HIP(hipMemcpyAsync(h, g->range_dev, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    QGX_HIP(hipMemsetAsync(g->range_dev, 0, sizeof(h), (hipStream_t)stream));
+    QGX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *flags = h[0];
+    memcpy(input_absmax, &h[1], sizeof(float));
+    return QGX_OK;
+}
+
+extern "C" int qgx_generator_info(const qgx_generator *g, int *precision, int *ascale_log2, int *fold, float *layer_absmax) {
+    QGX_REQUIRE(g, "qgx_generator_info: null generator");
+    if (precision) *precision = g->opt_precision;
+    if (ascale_log2) { int e = 0; (void)frexpf(g->opt_ascale, &e); *ascale_log2 = e - 1; }
+    if (fold) *fold = g->opt_fold;
+    if (layer_absmax) memcpy(layer_absmax, g->calib_max, sizeof(g->calib_max));
     return QGX_OK;
 }
 
@@ -1847,6 +2016,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
         }
     float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
     for (float *p : bufs) if (p) (void)hipFree(p);
+    if (g->range_dev) (void)hipFree(g->range_dev);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);
     delete g;
     return QGX_OK;
@@ -1862,6 +2032,8 @@ extern "C" int qgx_cnn_forward(qgx_generator *g, int inet, const float *x_dev, f
     QGX_REQUIRE(g && x_dev && y_dev && inet >= 0 && inet < g->n_nets && B > 0, "qgx_cnn_forward: bad argument");
     int rc = reserve(g, B, N);
     if (rc) return rc;
+    hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       (size_t)B * g->nets[inet].n_in * N * N, g->range_dev);
     return cnn_forward(g, g->nets[inet], x_dev, y_dev, B, N, (hipStream_t)stream);
 }
 
@@ -1911,7 +2083,8 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
-    else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= 0 && value <= 12, "ascale_log2 must be in 0..12"); g->opt_ascale = ldexpf(1.f, value); }
+    else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= -24 && value <= 24, "ascale_log2 must be in -24..24"); g->opt_ascale = ldexpf(1.f, value); }
+    else if (!strcmp(name, "auto")) { g->opt_precision = g->auto_precision; g->opt_fold = g->auto_fold; g->opt_ascale = ldexpf(1.f, g->auto_ascale_log2); }
     else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;

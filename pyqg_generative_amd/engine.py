@@ -62,6 +62,48 @@ class Generator:
     def noise_dtype(self):
         return torch.float64 if self.kind == 'gz' else torch.float32
 
+    # ---- f16x3 range guard ---------------------------------------------------------------------
+    def info(self):
+        """What the calibration at construction decided: dict(precision 0|3, ascale_log2, fold, layer_absmax)."""
+        p, e, f = C.c_int(0), C.c_int(0), C.c_int(0)
+        mx = (C.c_float * 10)()
+        check(lib.qgx_generator_info(self._h, C.byref(p), C.byref(e), C.byref(f), mx))
+        return dict(precision=p.value, ascale_log2=e.value, fold=f.value, layer_absmax=list(mx))
+
+    def range_read(self):
+        """Synchronise and return (flags, input_absmax) of the range guard since the last read; clears them.
+        flags bit l: conv layer l+1 stored an activation beyond the f16 range; bit 31: non-finite forcing."""
+        fl, mx = C.c_uint(0), C.c_float(0)
+        check(lib.qgx_generator_range_read(self._h, C.byref(fl), C.byref(mx), _stream()))
+        return fl.value, mx.value
+
+    def range_ok(self):
+        """-> None if every value stayed inside the 16-bit window since the last check, else a description."""
+        if self.info()['precision'] == 0:
+            self.range_read()
+            return None
+        flags, in_max = self.range_read()
+        if flags == 0 and in_max <= 65504.:
+            return None
+        layers = [l + 1 for l in range(8) if flags >> l & 1]
+        return (f'f16x3 generator arithmetic left its range: overflow in conv layer(s) {layers}, '
+                f'non-finite forcing: {bool(flags >> 31)}, largest |network input| {in_max:g}')
+
+    def _guarded(self, launch):
+        """Run `launch()`; if the 16-bit window was left, switch this generator to the exact-f32 kernels for good
+        and run it again, so that the caller always receives a float32-class result."""
+        out = launch()
+        if self.check_range:
+            why = self.range_ok()
+            if why is not None:
+                import warnings
+                warnings.warn(why + '; switching this generator to the exact-f32 kernels', RuntimeWarning)
+                self.set_option('precision', 0)
+                out = launch()
+        return out
+
+    check_range = True
+
     def forward(self, q, z, demean=True, out=None):
         """q: (B,2,N,N) float64 cuda; z: (B,2,N,N) float32 (float64 for gz) -> S (B,2,N,N) float64."""
         assert q.is_cuda and q.dtype == torch.float64 and q.is_contiguous() and q.dim() == 4
@@ -69,16 +111,22 @@ class Generator:
         B, _, N, _ = q.shape
         assert z.numel() == q.numel()
         S = out if out is not None else torch.empty_like(q)
-        check(lib.qgx_generator_forward(self._h, _ptr(q), _ptr(z), _ptr(S), B, N, int(bool(demean)), _stream()))
-        return S
+
+        def launch():
+            check(lib.qgx_generator_forward(self._h, _ptr(q), _ptr(z), _ptr(S), B, N, int(bool(demean)), _stream()))
+            return S
+        return self._guarded(launch)
 
     def cnn_forward(self, x, inet=0):
         """Raw AndrewCNN forward: x (B,n_in,N,N) float32 -> (B,2,N,N) float32."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == self.n_in
         B, _, N, _ = x.shape
         y = torch.empty((B, 2, N, N), dtype=torch.float32, device=x.device)
-        check(lib.qgx_cnn_forward(self._h, inet, _ptr(x), _ptr(y), B, N, _stream()))
-        return y
+
+        def launch():
+            check(lib.qgx_cnn_forward(self._h, inet, _ptr(x), _ptr(y), B, N, _stream()))
+            return y
+        return self._guarded(launch)
 
     def set_option(self, name, value):
         check(lib.qgx_generator_set_option(self._h, name.encode(), int(value)))
@@ -122,6 +170,7 @@ class EnsembleEngine:
         self.N, self.NK, self.B = int(nx), int(nx) // 2 + 1, int(n_members)
         self.device = torch.device('cuda', device)
         self._h = C.c_void_p(0)
+        self._generators = []           # generators used by step(): their range guard is read at status time
         check(lib.qgx_create(C.byref(cfg), C.byref(self._h)))
 
     # ---- tables -------------------------------------------------------------------
@@ -177,7 +226,16 @@ class EnsembleEngine:
         out = torch.empty((self.B, 2), dtype=torch.float64, device=self.device)
         check(lib.qgx_status_ke_cfl(self._h, _ptr(out), _stream()))
         out = out.cpu().numpy()
+        self.check_generators()
         return out[:, 0], out[:, 1]
+
+    def check_generators(self):
+        """The fused step cannot re-run a forcing after the fact: a generator that left its 16-bit window since the
+        last check has corrupted the members' state, so this raises (status / snapshot cadence of the run loop)."""
+        for g in self._generators:
+            why = g.range_ok() if g.check_range else None
+            if why is not None:
+                raise FloatingPointError(why + "; re-run with Generator.set_option('precision', 0)")
 
     # ---- time-averaged diagnostics --------------------------------------------------
     def diag_config(self, start_step, every):
@@ -206,6 +264,8 @@ class EnsembleEngine:
         if generator is not None or forcing is not None:
             p = _lib.qgx_param()
             p.gen = generator._h if generator is not None else None
+            if generator is not None and generator not in self._generators:
+                self._generators.append(generator)
             p.sampling = {'AR1': _lib.SAMPLING_AR1, 'constant': _lib.SAMPLING_CONSTANT}[sampling]
             p.nsteps = int(nsteps_decor)
             p.weight = float(weight)

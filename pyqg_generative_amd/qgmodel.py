@@ -317,6 +317,7 @@ class QGModel:
         xarray layout (xarray_output.py; reference call sites simulate.py:93,105,133,138).  ``variables``
         restricts the exported state fields (run_simulation exports only what survives drop_vars)."""
         from . import xarray_output
+        self._eng.check_generators()      # a snapshot of a state corrupted by a range overflow must not be written
         names = xarray_output.VARIABLES if variables is None else variables
         return xarray_output.model_to_dataset(self, fields={n: getattr(self, n) for n in names})
 

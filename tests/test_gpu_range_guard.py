@@ -1,0 +1,181 @@
+"""GPU: the f16x3 generator arithmetic at and beyond the edges of its value window.
+
+The default conv arithmetic carries float32 operands as f16 hi/lo pairs (float32-class inside a window of
+stored values: the hi part overflows above 65504, the lo part goes subnormal far below a layer's own scale).
+The shipped nets sit well inside; these tests use nets that do not:
+  * `weights.synthetic()` nets (random-init architecture);
+  * the shipped GAN with one layer's BatchNorm rescaled by 2^k (and the next conv by 2^-k: the SAME function),
+    so that a hidden activation tensor reaches ~3e4, or sinks to ~1e-6;
+  * a net whose layers differ by more than the window.
+`qgx_generator_create` must calibrate each of them to a float32-class configuration (or fall back to the
+exact-f32 kernels), and what calibration cannot foresee — an input far hotter than the calibration set — must be
+caught at run time by the range guard, never returned silently.
+Truth = `oracle.gen_ref.cnn_forward(dtype='float64')` on the same float32 parameters; bound = the float32 class
+(2e-5 of the output maximum, the tolerance of the golden-vector tests).
+"""
+import os
+import copy
+import warnings
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from conftest import GOLDEN
+from oracle import gen_ref
+
+
+def _shipped(kind='gan'):
+    from pyqg_generative_amd import weights
+    return weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind)
+
+
+def _oracle(net):
+    return gen_ref.CNNWeights(net['conv_w'], net['conv_b'], net['bn_g'], net['bn_b'], net['bn_m'], net['bn_v'])
+
+
+def _rescaled(net, layer, log2):
+    """multiply BatchNorm `layer`'s output by 2^log2 and the next conv's weights by 2^-log2: the same function of
+    the input, with that hidden tensor stored 2^log2 times larger"""
+    net = copy.deepcopy(net)
+    s = np.float32(2.0 ** log2)
+    net['bn_g'][layer] = net['bn_g'][layer] * s
+    net['bn_b'][layer] = net['bn_b'][layer] * s
+    net['conv_w'][layer + 1] = net['conv_w'][layer + 1] / s
+    return net
+
+
+def _maxrel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def _inputs(B, N, n_in=4, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(B, n_in, N, N).astype('float32')
+    x[:, :2] *= 1.5
+    return x
+
+
+def test_shipped_nets_calibrate_to_the_round1_configuration():
+    import pyqg_generative_amd as qa
+    for kind in ('gan', 'vae', 'gz'):
+        nets, xs, ys = _shipped(kind)
+        info = qa.Generator(kind, nets, xs, ys).info()
+        print(kind, info)
+        assert info['precision'] == 3 and info['ascale_log2'] == 0, (kind, info)
+        mx = [m for m in info['layer_absmax'][:7] if m > 0]
+        assert 0.25 <= min(mx) and max(mx) <= 1024
+
+
+@pytest.mark.parametrize('kind', ['gan', 'gz'])
+def test_synthetic_nets_are_float32_class(kind):
+    import pyqg_generative_amd as qa
+    from pyqg_generative_amd import weights
+    nets, xs, ys = weights.synthetic(kind, seed=3)
+    gen = qa.Generator(kind, nets, xs, ys)
+    info = gen.info()
+    N, B = 64, 16
+    x = _inputs(B, N, nets[0]['conv_w'][0].shape[1], seed=1)
+    xd = torch.as_tensor(x, device='cuda')
+    for inet, net in enumerate(nets):
+        truth = gen_ref.cnn_forward(_oracle(net), x[:3], dtype='float64')
+        err32 = _maxrel(gen_ref.cnn_forward(_oracle(net), x[:3]), truth)
+        y = gen.cnn_forward(xd, inet).cpu().numpy()
+        err = _maxrel(y[:3], truth)
+        print(f'\nsynthetic {kind} net{inet}: {info}  f16x3 err {err:.2e} (torch-f32 {err32:.2e})')
+        assert err < 2e-5 and err < 4 * err32 + 1e-7
+    assert gen.range_ok() is None
+
+
+@pytest.mark.parametrize('layer,log2', [(1, 8), (3, 8), (0, 7), (2, -18), (5, -20), (0, -16), ('all', -16), ('all', 7)])
+def test_rescaled_hidden_tensor_stays_float32_class(layer, log2):
+    """a hidden activation tensor pushed to ~3e4 (log2 = 7, 8: within a factor 2 of the f16 overflow if stored
+    unscaled) or down to ~1e-6 (lo parts would be flushed): calibration moves the pre-scale, the result keeps the
+    float32 error bound and the run-time guard stays quiet"""
+    import pyqg_generative_amd as qa
+    nets, xs, ys = _shipped('gan')
+    base = qa.Generator('gan', nets, xs, ys).info()['layer_absmax']
+    if layer == 'all':                                # every hidden tensor moved together: the pre-scale must follow
+        net = nets[0]
+        for l in range(7):
+            net = _rescaled(net, l, log2)
+        layer = 1
+    else:
+        net = _rescaled(nets[0], layer, log2)
+    gen = qa.Generator('gan', [net], xs, ys)
+    info = gen.info()
+    N, B = 64, 8
+    x = _inputs(B, N, seed=layer)
+    truth = gen_ref.cnn_forward(_oracle(net), x[:3], dtype='float64')
+    err32 = _maxrel(gen_ref.cnn_forward(_oracle(net), x[:3]), truth)
+    gen.check_range = False
+    y = gen.cnn_forward(torch.as_tensor(x, device='cuda')).cpu().numpy()
+    err = _maxrel(y[:3], truth)
+    print(f'\nlayer {layer + 1} x 2^{log2}: stored max {base[layer] * 2.0 ** log2:.3g}; {info["precision"]=}, '
+          f'{info["ascale_log2"]=}, {info["fold"]=}; err {err:.2e} (torch-f32 {err32:.2e})')
+    assert gen.range_ok() is None
+    assert err < 2e-5 and err < 4 * err32 + 1e-7
+    if info['precision'] == 3 and not (layer == 0 and info['fold']):
+        assert info['ascale_log2'] != 0               # the window had to move (a folded layer-1 BatchNorm is never stored)
+
+
+def test_net_wider_than_the_window_falls_back_to_exact_f32():
+    """one hidden tensor at ~3e4 and another at ~1e-4: no single pre-scale makes f16x3 float32-class, so the
+    exact-f32 kernels become this generator's default — by itself"""
+    import pyqg_generative_amd as qa
+    nets, xs, ys = _shipped('gan')
+    net = _rescaled(_rescaled(nets[0], 1, 8), 4, -16)
+    gen = qa.Generator('gan', [net], xs, ys)
+    info = gen.info()
+    assert info['precision'] == 0, info
+    x = _inputs(8, 64, seed=5)
+    truth = gen_ref.cnn_forward(_oracle(net), x[:3], dtype='float64')
+    y = gen.cnn_forward(torch.as_tensor(x, device='cuda')).cpu().numpy()
+    assert _maxrel(y[:3], truth) < 2e-5
+
+
+def test_runtime_guard_catches_an_overflow_and_recovers():
+    """inputs 2000x hotter than anything calibration saw overflow the 16-bit window: the stand-alone forward
+    notices (sticky device flag), switches to the exact-f32 kernels and returns the float32-class result; the fused
+    online step cannot undo a step and raises at the next status check instead"""
+    import pyqg_generative_amd as qa
+    from pyqg_generative_amd import _lib as L
+    nets, xs, ys = _shipped('gan')
+    gen = qa.Generator('gan', nets, xs, ys)
+    N, B = 64, 8
+    x = _inputs(B, N, seed=9) * 2000.0
+    truth = gen_ref.cnn_forward(_oracle(nets[0]), x[:2], dtype='float64')
+    gen.check_range = False
+    bad = gen.cnn_forward(torch.as_tensor(x, device='cuda')).cpu().numpy()
+    why = gen.range_ok()
+    assert why is not None and 'overflow' in why
+    assert not (_maxrel(bad[:2], truth) < 2e-5)            # the unguarded result is wrong (or not finite)
+    gen.check_range = True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        y = gen.cnn_forward(torch.as_tensor(x, device='cuda')).cpu().numpy()
+    assert any('exact-f32' in str(i.message) for i in w)
+    assert gen.info()['precision'] == 0 and _maxrel(y[:2], truth) < 2e-5
+    # NaN / inf inputs are reported as an out-of-range input
+    gen.set_option('auto', 1)
+    assert gen.info()['precision'] == 3
+    gen.check_range = False
+    xn = _inputs(B, N, seed=1)
+    xn[3, 1, 5, 7] = np.nan
+    gen.cnn_forward(torch.as_tensor(xn, device='cuda'))
+    assert gen.range_ok() is not None
+    # fused online step: PV 5000x the eddy amplitude drives q / x_std out of the window
+    gen2 = qa.Generator('gan', nets, xs, ys)
+    e = qa.EnsembleEngine(nx=N, n_members=4, dt=1.0)
+    e.set_q(np.random.RandomState(0).randn(4, 2, N, N) * np.array([8e-6, 1e-6])[None, :, None, None] * 5000)
+    e.step(1, generator=gen2, sampling='constant', nsteps_decor=1, seed=1)
+    with pytest.raises(FloatingPointError):
+        e.status()
+    # ... and a healthy run passes the same check
+    gen3 = qa.Generator('gan', nets, xs, ys)
+    e = qa.EnsembleEngine(nx=N, n_members=4, dt=14400.)
+    e.set_q(np.random.RandomState(0).randn(4, 2, N, N) * np.array([8e-6, 1e-6])[None, :, None, None])
+    e.step(3, generator=gen3, sampling='constant', nsteps_decor=1, seed=1)
+    ke, cfl = e.status()
+    assert np.isfinite(ke).all()
