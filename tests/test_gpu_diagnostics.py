@@ -74,7 +74,10 @@ def test_paramspec_and_dataset_export():
         assert np.abs(g - rr).max() <= 1e-9 * np.abs(rr).max(), name
         parts = parts + g
     assert np.abs(parts - got).max() <= 1e-10 * np.abs(got).max()
-    ds = snapshot_dataset(m)
-    assert ds['KEspec'].shape == (2, N, N // 2 + 1) and ds['KEflux'].shape == (N, N // 2 + 1)
+    ds = snapshot_dataset(m)           # one snapshot: pyqg's layout, every variable with a length-one time axis
+    assert ds['KEspec'].shape == (1, 2, N, N // 2 + 1) and ds['KEflux'].shape == (1, N, N // 2 + 1)
     assert ds['q'].shape == (1, 2, N, N)
+    from pyqg_generative_amd.tools.simulate import concat_in_time
+    full = concat_in_time([ds, ds])    # the run's dataset: spectra from the last snapshot, no time axis
+    assert full['KEspec'].shape == (2, N, N // 2 + 1) and full['paramspec_KEflux'].shape == (N, N // 2 + 1)
     m.close()
