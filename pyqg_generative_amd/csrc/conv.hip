@@ -618,7 +618,8 @@ __global__ __launch_bounds__(256) void k_conv_last(ConvArgs a, LastWeights lw) {
 // order like their bit patterns, so one atomicMax on the bits per wave keeps the running maximum
 __device__ __forceinline__ void input_absmax(float m, unsigned *range) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(range + 1, __float_as_uint(m));
+    // the running maximum settles after the first launches: read it, and only a new record costs an atomic
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > __builtin_nontemporal_load(range + 1)) atomicMax(range + 1, __float_as_uint(m));
 }
 __device__ __forceinline__ float abs_or_inf(float x) { return x != x ? __uint_as_float(0x7f800000u) : fabsf(x); }
 

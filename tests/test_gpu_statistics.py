@@ -4,8 +4,9 @@ North-star criterion "KE-spectrum match to the CPU reference": the ensemble- and
 spectrum (reference's metric: calc_ispec(m, 0.5*ave_lev(KEspec)), online-simulations.ipynb cell 25) of a
 GPU ensemble against the CPU oracle run to equilibrium, and the equilibrium KE against the reference's
 published log (notebooks/3-2-dealiasing.ipynb:1412-1455: KE 4.6e-4..5.4e-4 for the 64x64 eddy run).
-Stated tolerance: 35 % per wavenumber bin over the energy-containing range (two independent finite samples
-of a turbulent flow), 25 % on the equilibrium kinetic energy."""
+Stated tolerance: 20 % per wavenumber bin over the energy-containing range (a 16-member GPU ensemble against an
+8-member CPU ensemble, each time-averaged over 3000 steps: two independent finite samples of a turbulent flow),
+15 % on the equilibrium kinetic energy."""
 import numpy as np
 import pytest
 
@@ -29,21 +30,23 @@ def test_eddy_equilibrium_ke_spectrum_matches_cpu_oracle():
     # equilibrium KE of every member in the published band (unseeded reference run: 4.6e-4 .. 5.4e-4)
     assert 3.5e-4 < ke_gpu.mean() < 6.5e-4, ke_gpu
     spec_gpu = m.ensemble_mean_diagnostic('KEspec')
-    # CPU oracle: two members, same configuration, different seeds
+    # CPU oracle: eight members, same configuration, different seeds (runs once, ~25 s of host time)
     specs, kes = [], []
-    for seed in (1, 2):
+    for seed in range(1, 9):
         r = qg_ref.QGModelRef(**kw)
         qg_ref.set_initial_condition(r, np.random.RandomState(seed))
         r.run()
         specs.append(r.get_diagnostic('KEspec'))
         kes.append(r._calc_ke())
     spec_cpu = np.mean(specs, axis=0)
-    assert abs(ke_gpu.mean() - np.mean(kes)) < 0.25 * np.mean(kes)
+    print(f'\nequilibrium KE: GPU {ke_gpu.mean():.3e} (16 members), CPU oracle {np.mean(kes):.3e} (8 members)')
+    assert abs(ke_gpu.mean() - np.mean(kes)) < 0.15 * np.mean(kes)
     kr, iso_gpu = spectral_ref.ke_spectrum(r, spec_gpu, m.delta)
     _, iso_cpu = spectral_ref.ke_spectrum(r, spec_cpu, m.delta)
     band = (kr > 2 * r.dk) & (kr < 20 * r.dk)                  # energy-containing range
     rel = np.abs(iso_gpu[band] - iso_cpu[band]) / iso_cpu[band]
-    assert rel.max() < 0.35, rel
+    print('relative difference of the isotropic KE spectrum per bin:', np.round(rel, 3))
+    assert rel.max() < 0.20, rel
     # total KE from the spectrum is consistent with the Parseval status value at the end of the run
     assert 0.5 < (iso_gpu.sum() * (kr[1] - kr[0])) / ke_gpu.mean() < 2.0
     m.close()

@@ -88,3 +88,102 @@ def test_ab3_startup_and_history_rotation():
         m._step_forward()
         assert m.dqhdt_pp is prev
     assert levels == [0, 1, 2, 2]
+
+
+def _unstable_mode(m, kx, ly):
+    """most unstable eigenpair of the linearised two-layer operator at wavenumber (k, l) for the model's
+    parameters: dq/dt = L q with L = -ik (U + Qy A(kappa^2)) + bottom drag on layer 2"""
+    k, l = m.kk[kx], m.ll[ly]
+    K2 = k * k + l * l
+    A = np.array([[-(K2 + m.F2), -m.F1], [-m.F2, -(K2 + m.F1)]]) / (K2 * (K2 + m.F1 + m.F2))
+    Lmat = -1j * k * (np.diag(m.Ubg) + np.diag(m.Qy) @ A)
+    Lmat[1, :] += m.rek * K2 * A[1, :]
+    w, vec = np.linalg.eig(Lmat)
+    i = np.argmax(w.real)
+    return w[i], vec[:, i]
+
+
+def test_linear_growth_rates_oblique_modes_and_jet_parameters():
+    """analytic Phillips growth (or decay) rate AND phase speed at several (k, l), l != 0 included, for the eddy and the
+    jet parameter sets (tools/parameters.py:26-27,37) at the grid sizes of BASELINE's configs"""
+    jet = dict(rek=7e-8, delta=0.1, beta=1e-11)
+    for N, params, modes in ((64, {}, [(4, 0), (3, 2), (5, -3)]), (96, jet, [(4, 0), (6, 3), (3, -2)]),
+                             (48, {}, [(3, 1)])):
+        for kx, ly in modes:
+            m = qg_ref.QGModelRef(nx=N, dt=1800., filterfac=0., **params)
+            w, vec = _unstable_mode(m, kx, ly)
+            qh = np.zeros((2, N, N // 2 + 1), complex)
+            qh[:, ly, kx] = 1e-12 * N * N * vec
+            m.set_qh(qh)
+            nsteps = 300
+            a0 = m.qh[:, ly, kx].copy()
+            for _ in range(nsteps):
+                m._step_forward()
+            ratio = m.qh[:, ly, kx] / a0
+            T = nsteps * m.dt
+            np.testing.assert_allclose(np.log(np.abs(ratio)) / T, w.real, rtol=3e-4, err_msg=str((N, kx, ly)))
+            # phase: exp(i Im(w) T), compared modulo 2 pi through the complex ratio
+            np.testing.assert_allclose(ratio / np.abs(ratio), np.exp(1j * w.imag * T) * np.ones(2), atol=2e-3)
+            # no other mode was excited (the step is linear in a single small wave)
+            rest = np.abs(m.qh).copy()
+            rest[:, ly, kx] = 0
+            assert rest.max() < 1e-9 * np.abs(m.qh[:, ly, kx]).max()
+
+
+def _hermitian_sum(x):
+    """sum over the full wavenumber plane of a half-plane (l, k >= 0) real density"""
+    w = np.full(x.shape[-1], 2.0)
+    w[0] = w[-1] = 1.0
+    return float((x * w).sum())
+
+
+def test_energy_budget_of_the_diagnostics_closes():
+    """The ten spectral diagnostics are a decomposition of the energy tendency: with
+    E = -1/2 sum_k (H_k/H) <psi_k q_k>, dE/dt = -sum_k (H_k/H) Re(conj(psi_k) dq_k/dt) / M^2 summed over the
+    plane must equal sum(KEflux + APEflux + APEgenspec + KEfrictionspec + paramspec) — to round-off, for the
+    tendency the model actually steps with (before the filter).  The nonlinear fluxes only redistribute:
+    sum(KEflux) = 0 on any field; sum(APEflux) = 0 once cubic products are alias-free (kappa < N/4)."""
+    N = 64
+    rs = np.random.RandomState(5)
+    S = rs.randn(2, N, N) * np.array([7e-12, 2e-13])[:, None, None]
+    for band, params in ((1. / 4., {}), (2. / 3., dict(rek=7e-8, delta=0.1, beta=1e-11))):
+        m = qg_ref.QGModelRef(nx=N, dt=14400., parameterization=lambda mm: S, **params)
+        q = rs.randn(2, N, N) * np.array([8e-6, 1e-6])[:, None, None]
+        qh = np.fft.rfftn(q, axes=(-2, -1)) * (m.wv < band * m.kk[-1])
+        m.set_qh(qh)
+        m._invert()
+        m._do_advection()
+        m._do_friction()
+        m._do_q_subgrid_parameterization()
+        d = m._diag_functions()
+        dEdt = -_hermitian_sum(((m.Hi / m.H)[:, None, None] * np.real(np.conj(m.ph) * m.dqhdt)).sum(0)) / m.M ** 2
+        parts = {k: _hermitian_sum(d[k]) for k in ('KEflux', 'APEflux', 'APEgenspec', 'KEfrictionspec', 'paramspec')}
+        scale = sum(abs(_hermitian_sum(np.abs(d[k]))) for k in parts)
+        assert abs(sum(parts.values()) - dEdt) < 1e-12 * scale, (band, parts, dEdt)
+        assert abs(parts['KEflux']) < 1e-12 * _hermitian_sum(np.abs(d['KEflux']))
+        if band <= 0.25:
+            assert abs(parts['APEflux']) < 1e-12 * _hermitian_sum(np.abs(d['APEflux']))
+        assert parts['KEfrictionspec'] < 0                     # bottom drag only removes energy
+        # the parameterization's APE / KE split sums to its total contribution, wavenumber by wavenumber
+        np.testing.assert_allclose(d['paramspec_APEflux'] + d['paramspec_KEflux'], d['paramspec'],
+                                   atol=1e-12 * np.abs(d['paramspec']).max())
+        # KEspec / Ensspec are the spectra of what their names say (Parseval against the grid fields)
+        ke_grid = 0.5 * ((m.u ** 2 + m.v ** 2).mean(axis=(1, 2)))
+        np.testing.assert_allclose([0.5 * _hermitian_sum(d['KEspec'][z]) for z in (0, 1)], ke_grid, rtol=1e-10)
+        np.testing.assert_allclose([_hermitian_sum(d['Ensspec'][z]) for z in (0, 1)], (m.q ** 2).mean(axis=(1, 2)), rtol=1e-10)
+
+
+def test_published_48x48_log_is_reproduced():
+    """Google-Colab/online-simulations.ipynb:318-347 (48 x 48, dt = 7200 s): CFL 0.009 while the flow is at
+    rest, KE growing by x2.8-2.9 per 1000 steps late in the linear stage (the printed run carries the GAN
+    parameterization, whose forcing is negligible at those amplitudes), saturation near step 9000-11000."""
+    m = qg_ref.QGModelRef(nx=48, dt=7200., tmax=7200. * 8000, twrite=1000)
+    qg_ref.set_initial_condition(m, np.random.RandomState(0))
+    ke = {}
+    for t in m.run_with_snapshots(tsnapint=7200. * 1000):
+        ke[m.tc] = m._calc_ke()
+        if m.tc == 1000:
+            assert abs(m.cfl - 0.009) < 5e-4
+    for a, b in ((4000, 5000), (5000, 6000), (6000, 7000)):
+        assert 2.4 < ke[b] / ke[a] < 3.4, (a, b, ke[b] / ke[a])
+    assert 1e-8 < ke[1000] < 5e-6          # published: 1.4e-7 .. 5.7e-7 at step 1000 (unseeded initial conditions)
