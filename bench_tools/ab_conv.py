@@ -11,6 +11,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the A/B library (make -C pyqg_generative_amd/csrc ab) carries every kernel variant; the product library only
+# the fastest path per layer and size
+_AB = os.path.join(ROOT, 'pyqg_generative_amd', 'libqgx_ab.so')
+if 'QGX_LIB' not in os.environ and os.path.exists(_AB):
+    os.environ['QGX_LIB'] = _AB
 import pyqg_generative_amd as qa
 from pyqg_generative_amd import weights
 

@@ -44,8 +44,13 @@ extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
 #include "conv_half.hpp"
 #include "conv_pair.hpp"
+// Kernel variants that were measured slower than the ones above (k_convh generic / plain f16, k_convh_res,
+// k_convh3 on 16x16x32 MFMAs, k_convh4 with full-line chunks) are compiled only into the A/B library
+// (`make ab` -> libqgx_ab.so, bench_tools/ab_conv.py): the product library carries one path per layer and size.
+#ifdef QGX_AB
 #include "conv_h16.hpp"
 #include "conv_h4.hpp"
+#endif
 
 // OUTH = 0: f32 NHWC output.  OUTH = 1 / 2 (first layer only): the MFMA roles are swapped (lane = pixel)
 // and the epilogue writes the packed f16 / f16 hi-lo activation layout of conv_half.hpp.
@@ -989,8 +994,11 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
             if ((rc = upf(cc == 16 ? L.wl16 : L.wl8, pw))) return rc;
         }
         if (li < 7) {
-            if ((rc = pack_half(L, li, w, 1)) || (rc = pack_half(L, li, w, 2))) return rc;
+            if ((rc = pack_half(L, li, w, 2))) return rc;
+#ifdef QGX_AB
+            if ((rc = pack_half(L, li, w, 1))) return rc;
             if (li == 1 && (rc = pack_half16(L, li, w))) return rc;
+#endif
             if (li == 1) {
                 // fold layer 1's BatchNorm (alpha, beta' of its 128 output channels) into this layer
                 const int cin = L.cin, T = L.ks * L.ks;
@@ -1007,7 +1015,9 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
                     bf[co] = (float)acc;
                 }
                 if ((rc = pack_half(L, li, w, 2, al.data())) || (rc = upf(L.biasF, bf))) return rc;
+#ifdef QGX_AB
                 if ((rc = pack_half16(L, li, w, al.data()))) return rc;
+#endif
             }
         } else if ((rc = pack_half(L, li, w, 2))) return rc;      // fused (layer 7, layer 8) pair
     }
@@ -1273,6 +1283,10 @@ static int rows_h2(int N) {
 // k_convh2 is specialised for, so it is always taken there ("half_min_tiles" = 1; raise it to send small
 // ensembles to the exact-f32 split-K kernels)
 static bool half_path_ok(const qgx_generator *g, int B, int N) {
+#ifndef QGX_AB
+    // product library: f16x3 on the grids k_convh2 is specialised for, exact f32 everywhere else
+    if (g->opt_precision != 3 || g->opt_h2 != 3 || rows_h2(N) <= 0) return false;
+#endif
     if (N > 128 || choose_rows(N) <= 0) return false;
     int R = (g->opt_h2 == 3 && g->opt_precision == 3) ? rows_h2(N) : 0;
     if (R == 0) R = g->opt_half_nw == 4 ? choose_rows(N) : rows_half(N);
@@ -1280,6 +1294,7 @@ static bool half_path_ok(const qgx_generator *g, int B, int N) {
     return B * (N / R) >= g->opt_half_min_tiles;
 }
 
+#ifdef QGX_AB
 template <int CIN, int COUT, int KS, int NS, bool OUTF32>
 static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
                         hipStream_t st) {
@@ -1327,6 +1342,8 @@ static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const v
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
 }
+
+#endif  // QGX_AB
 
 static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *in, float *out, int B, int N,
                             int n_out, hipStream_t st);
@@ -1496,6 +1513,7 @@ static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const 
     }
 }
 
+#ifdef QGX_AB
 // 3x3 layers, f16x3, resident weights (k_convh_res); done = false when the tile does not fit in LDS
 template <int CIN, int COUT, bool OUTF32>
 static int launch_convh_res(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
@@ -1533,6 +1551,8 @@ static int launch_convh_res(qgx_generator *g, int layer, const LayerHost &L, con
     return QGX_OK;
 }
 
+#endif  // QGX_AB
+
 template <int CIN, int COUT, int NS, bool OUTF32>
 static int conv3x3_half(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
                         hipStream_t st) {
@@ -1541,14 +1561,19 @@ static int conv3x3_half(qgx_generator *g, int layer, const LayerHost &L, const v
         int rc = launch_convh2<CIN, COUT, 3, OUTF32>(g, layer, L, in, out, B, N, st, done);
         if (rc || done) return rc;
     }
+#ifdef QGX_AB
     if (NS == 2 && g->opt_res) {
         bool done = false;
         int rc = launch_convh_res<CIN, COUT, OUTF32>(g, layer, L, in, out, B, N, st, done);
         if (rc || done) return rc;
     }
     return launch_convh<CIN, COUT, 3, NS, OUTF32>(g, layer, L, in, out, B, N, st);
+#else
+    QGX_REQUIRE(false, "generator: no f16x3 kernel for N=%d (half_path_ok admits only the specialised grids)", N);
+#endif
 }
 
+#ifdef QGX_AB
 // the 128 -> 64, 5x5 layer on 16x16x32 MFMAs (k_convh3); grids whose rows tile 256 pixels
 static int launch_convh3(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, int N,
                          hipStream_t st, bool &done) {
@@ -1609,6 +1634,8 @@ static int launch_convh4(qgx_generator *g, int layer, const LayerHost &L, const 
 }
 
 // two fused 3x3 layers (k_convh_pair); 64 x 64 grids
+#endif  // QGX_AB
+
 template <int CINA, bool LAST, bool BOUTF32>
 static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, const LayerHost &LB, const void *in,
                              void *out, int B, int N, int n_out, hipStream_t st) {
@@ -1712,10 +1739,16 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         const bool tiny = NS == 2 && g->opt_h2 == 3 && r2 > 0 && Bc * (N / r2) < g->opt_part_max_tiles;
         bool done1 = false;
         if (tiny && (rc = launch_convh2_part<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+#ifdef QGX_AB
         if (!done1 && NS == 2 && g->opt_h4 && (rc = launch_convh4(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+#endif
         if (!done1 && NS == 2 && (g->opt_h2 & 2) && (rc = launch_convh2<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+#ifdef QGX_AB
         if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, L1, A, Bb, Bc, N, st))) return rc;
+#else
+        QGX_REQUIRE(done1, "generator: no f16x3 kernel for N=%d", N);
+#endif
         if (tiny) {
             bool done2 = false;
             if ((rc = launch_convh2_part<64, 32, 3, false>(g, 2, net.L[2], Bb, A, Bc, N, st, done2))) return rc;
@@ -1783,7 +1816,11 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
                        hipStream_t st) {
     int rc;
     if (g->opt_precision && half_path_ok(g, B, N))
+#ifdef QGX_AB
         return g->opt_precision == 1 ? cnn_forward_half<1>(g, net, x, y, B, N, st) : cnn_forward_half<2>(g, net, x, y, B, N, st);
+#else
+        return cnn_forward_half<2>(g, net, x, y, B, N, st);
+#endif
     float *A = g->actA, *Bb = g->actB;
     if (net.n_in == 4) rc = g->opt_first_split == 2 ? launch_conv<4, 128, 5, 4, true, false, 2>(g, 0, net.L[0], x, A, B, N, 128, st)
                        : g->opt_first_split == 4 ? launch_conv<4, 128, 5, 4, true, false, 4>(g, 0, net.L[0], x, A, B, N, 128, st)
@@ -2066,6 +2103,11 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "last_valu")) g->opt_last_valu = value ? 1 : 0;
     else if (!strcmp(name, "small")) g->opt_small = value ? 1 : 0;
     else if (!strcmp(name, "v3")) g->opt_v3 = value;   // -1 auto, 0 off, 1 = slice per tap row, 2 = per chunk
+#ifndef QGX_AB
+    else if (!strcmp(name, "res") || !strcmp(name, "h3") || !strcmp(name, "h4") || !strcmp(name, "half_nw") ||
+             !strcmp(name, "h2") || (!strcmp(name, "precision") && value == 1))
+        QGX_REQUIRE(false, "generator option '%s'=%d selects a kernel of the A/B library only (make ab, QGX_LIB=libqgx_ab.so)", name, value);
+#endif
     else if (!strcmp(name, "precision")) { QGX_REQUIRE(value == 0 || value == 1 || value == 3, "precision must be 0 (f32), 1 (f16) or 3 (f16x3)"); g->opt_precision = value; }
     else if (!strcmp(name, "member_chunk")) { QGX_REQUIRE(value >= 0, "member_chunk must be >= 0"); g->opt_member_chunk = value; }
     else if (!strcmp(name, "res")) g->opt_res = value ? 1 : 0;

@@ -146,6 +146,7 @@ __device__ __forceinline__ void store_tile_t(const f32x16 &acc, int cb, int h, c
     }
 }
 
+#ifdef QGX_AB   // generic run-time-N kernel (and the plain-f16 mode): A/B builds only, see conv.hip
 template <int CIN, int COUT, int KS, int NS, int MT, int TPS, int PPT, bool OUTF32, int NW = 8, bool SWZ = false>
 __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles) {
     constexpr int NTHR = NW * 64;
@@ -386,6 +387,8 @@ __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles)
 #undef QGX_HP_ADDR
 #undef QGX_HP_FRAG
 }
+
+#endif  // QGX_AB
 
 // ---- f16x3 hidden layers, compile-time grid size: 4 waves x 2 workgroups per CU ---------------------------
 // Same arithmetic and data layouts as k_convh<NS = 2>, built so that TWO workgroups share a CU and run
@@ -933,6 +936,7 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
 #undef QGX_F_STORE
 }
 
+#ifdef QGX_AB   // resident-weight 3x3 kernel: measured no faster than k_convh2, A/B builds only
 // ---- 3x3 hidden layers with RESIDENT weights (f16x3) ------------------------------------------------------
 // The 3x3 layers are small (<= 73.7 KB of hi/lo weights), so a persistent 8-wave workgroup keeps the
 // whole weight set in LDS and stages only the input patch: 32 channels (128 bytes: 4 octets x hi/lo) per
@@ -1100,3 +1104,4 @@ __global__ __launch_bounds__(512) void k_convh_res(ConvHArgs a, int total_tiles)
 #undef QGX_RP_LOAD
 #undef QGX_RP_STORE
 }
+#endif  // QGX_AB

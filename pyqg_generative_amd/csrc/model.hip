@@ -128,7 +128,11 @@ __global__ void k_status(SpecDev d, const double2 *ph, const double *u, const do
 using namespace qgx;
 
 extern "C" const char *qgx_last_error(void) { return g_err; }
-extern "C" const char *qgx_version(void) { return "qgx 0.1 (gfx950)"; }
+#ifdef QGX_AB
+extern "C" const char *qgx_version(void) { return "qgx 0.2 (gfx950) +ab"; }     // A/B library: every kernel variant
+#else
+extern "C" const char *qgx_version(void) { return "qgx 0.2 (gfx950)"; }
+#endif
 
 extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
     QGX_REQUIRE(cfg && out, "qgx_create: null argument");

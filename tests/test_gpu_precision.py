@@ -7,9 +7,11 @@ them in double precision, so |result - truth| is the rounding error of an evalua
     float32 error class: it has to pass the SAME 2e-5 golden-vector tolerance as precision 0 and
     its error against the float64 truth may not exceed 4x that of the reference's own float32
     evaluation (torch CPU) on the same input
-  * precision 1: plain f16 operands (TF32-class, 2^-11 operand rounding): 1e-2 of the field maximum
+  * precision 1: plain f16 operands (TF32-class, 2^-11 operand rounding): 1e-2 of the field maximum; a mode of the
+    A/B library only (test_ab_library_variants_agree)
 """
 import os
+import sys
 import numpy as np
 import pytest
 
@@ -54,17 +56,16 @@ def test_split_f16_is_float32_class(kind, N, B):
         ref32 = gen_ref.cnn_forward(w, x[:4])
         err_ref = _maxrel(ref32, truth)
         errs = {}
-        for prec in (0, 3, 1):
+        for prec in (0, 3):
             gen.set_option('precision', prec)
             y = gen.cnn_forward(xd, inet).cpu().numpy()
             errs[prec] = _maxrel(y[:4], truth)
         gen.set_option('precision', 0)
         print(f'\n{kind} net{inet} N={N}: max err / max|y| vs float64 truth: torch-f32 {err_ref:.2e}, '
-              f'f32 MFMA {errs[0]:.2e}, f16x3 {errs[3]:.2e}, f16 {errs[1]:.2e}')
+              f'f32 MFMA {errs[0]:.2e}, f16x3 {errs[3]:.2e}')
         assert errs[0] < 2e-5
         assert errs[3] < 2e-5
         assert errs[3] < 4 * max(err_ref, errs[0]) + 1e-7
-        assert errs[1] < 1e-2
 
 
 @pytest.mark.parametrize('kind', ['gan', 'vae', 'gz'])
@@ -92,49 +93,100 @@ def test_split_f16_golden_vectors(kind):
         assert err < 2e-5
 
 
-VARIANTS = [
+VARIANTS = [                                     # selectable variants of the product library
     dict(part_max_tiles=100000),                 # split-K on the wide layers (single-member path)
-    dict(h2=0, half_nw=8, res=0, fuse=0),        # generic run-time-N kernel k_convh, 8 waves
-    dict(h2=0, half_nw=4, res=0, fuse=0),        # ... 4 waves, swizzled 64-byte patch pixels
-    dict(h2=0, half_nw=8, res=1, fuse=0),        # resident-weight 3x3 kernel k_convh_res
-    dict(h2=3, pair=0, fuse=0),                  # k_convh2 without the line-pair fetch
-    dict(h2=3, fuse=7),                          # every 3x3 pair fused (k_convh_pair)
-    dict(h2=3, fuse=2),
-    dict(h3=1),                                  # 5x5 layer on 16x16x32 MFMAs (k_convh3)
-    dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
+    dict(pair=0, fuse=0),                        # k_convh2 without the line-pair fetch
+    dict(fuse=7),                                # every 3x3 pair fused (k_convh_pair)
+    dict(fuse=2), dict(fuse=0),
     dict(h2_w8=0), dict(h2_w8=1),                # 4-wave x 2 workgroups per CU instead of one 8-wave workgroup
     dict(first_h=0),                             # exact-f32 first layer writing the 16-bit layout
     dict(fold=0),                                # layer 1's BatchNorm applied in its epilogue instead of folded into layer 2
     dict(member_chunk=16),                       # member sub-batches
+    dict(ascale_log2=3), dict(ascale_log2=-2),   # another activation pre-scale inside the window
 ]
+AB_VARIANTS = [                                  # kernels of the A/B library only (libqgx_ab.so, `make ab`)
+    dict(h2=0, half_nw=8, res=0, fuse=0),        # generic run-time-N kernel k_convh, 8 waves
+    dict(h2=0, half_nw=4, res=0, fuse=0),        # ... 4 waves, swizzled 64-byte patch pixels
+    dict(h2=0, half_nw=8, res=1, fuse=0),        # resident-weight 3x3 kernel k_convh_res
+    dict(h3=1),                                  # 5x5 layer on 16x16x32 MFMAs (k_convh3)
+    dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
+]
+DEFAULTS = dict(fuse=3, pair=1, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h2_w8=3, ascale_log2=0)
+AB_DEFAULTS = dict(DEFAULTS, h2=3, half_nw=8, res=1, h3=0, h4=0)
+
+
+def _variant_errors(gen, x, variants, defaults):
+    gen.check_range = False
+    gen.set_option('precision', 0)
+    ref = gen.cnn_forward(x).cpu().numpy()
+    gen.set_option('precision', 3)
+    errs = []
+    for v in variants:
+        for k, d in defaults.items():
+            gen.set_option(k, v.get(k, d))
+        errs.append(_maxrel(gen.cnn_forward(x).cpu().numpy(), ref))
+    return ref, errs
 
 
 @pytest.mark.parametrize('N,B', [(64, 32), (96, 8), (48, 16)])
 def test_optional_kernel_variants_agree(N, B):
-    """every selectable f16x3 kernel variant against the exact-f32 path: float32 tolerance (2e-5 of the
-    maximum); options that do not apply to a grid size fall back to the default kernels"""
+    """every selectable f16x3 kernel variant of the product library against the exact-f32 path: float32
+    tolerance (2e-5 of the maximum); options that do not apply to a grid size fall back to the default kernels"""
+    from pyqg_generative_amd import _lib
     gen = _gpu_generator('gan')
     rs = np.random.RandomState(7 * N + B)
     x = torch.as_tensor(rs.randn(B, 4, N, N).astype('float32'), device='cuda')
-    gen.set_option('precision', 0)
-    ref = gen.cnn_forward(x).cpu().numpy()
-    gen.set_option('precision', 3)
-    gen.set_option('part_max_tiles', 0)
-    defaults = dict(h2=3, half_nw=8, res=1, fuse=3, pair=1, h3=0, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h4=0, h2_w8=3)
-    for v in VARIANTS:
-        for k, d in defaults.items():
-            gen.set_option(k, v.get(k, d))
-        y = gen.cnn_forward(x).cpu().numpy()
-        err = _maxrel(y, ref)
+    _, errs = _variant_errors(gen, x, VARIANTS, DEFAULTS)
+    for v, err in zip(VARIANTS, errs):
         assert err < 2e-5, (v, err)
-    # plain f16 operands through the generic kernels (both wave counts): TF32-class tolerance
-    gen.set_option('precision', 1)
-    for nw in (8, 4):
-        for k, d in defaults.items():
-            gen.set_option(k, d)
-        gen.set_option('half_nw', nw)
-        err = _maxrel(gen.cnn_forward(x).cpu().numpy(), ref)
-        assert err < 1e-2, (nw, err)
+    assert gen.range_ok() is None
+    if b'+ab' not in _lib.lib.qgx_version():
+        # the product library refuses options that select A/B-only kernels instead of silently ignoring them
+        with pytest.raises(_lib.QgxError):
+            gen.set_option('h3', 1)
+        with pytest.raises(_lib.QgxError):
+            gen.set_option('precision', 1)
+
+
+def test_ab_library_variants_agree():
+    """the measured-slower kernels kept for A/B timing (k_convh, k_convh_res, k_convh3, k_convh4, plain-f16 mode)
+    still compute the same function: run in a child process on libqgx_ab.so (QGX_LIB)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ab = os.path.join(root, 'pyqg_generative_amd', 'libqgx_ab.so')
+    if not os.path.exists(ab):
+        pytest.skip('libqgx_ab.so is not built (make -C pyqg_generative_amd/csrc ab)')
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), 'ab-child'], env=dict(os.environ, QGX_LIB=ab),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out['version'].endswith('+ab')
+    for key, errs in out['f16x3'].items():
+        assert max(errs) < 2e-5, (key, errs)
+    for key, errs in out['f16'].items():
+        assert max(errs) < 1e-2, (key, errs)          # plain f16 operands: TF32-class tolerance
+
+
+def _ab_child():
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pyqg_generative_amd import _lib
+    out = {'version': _lib.lib.qgx_version().decode(), 'f16x3': {}, 'f16': {}}
+    for N, B in ((64, 32), (96, 8), (48, 16)):
+        gen = _gpu_generator('gan')
+        rs = np.random.RandomState(7 * N + B)
+        x = torch.as_tensor(rs.randn(B, 4, N, N).astype('float32'), device='cuda')
+        ref, errs = _variant_errors(gen, x, VARIANTS + AB_VARIANTS, AB_DEFAULTS)
+        out['f16x3'][f'{N}x{B}'] = errs
+        gen.set_option('precision', 1)
+        e16 = []
+        for nw in (8, 4):
+            for k, d in AB_DEFAULTS.items():
+                gen.set_option(k, d)
+            gen.set_option('half_nw', nw)
+            e16.append(_maxrel(gen.cnn_forward(x).cpu().numpy(), ref))
+        out['f16'][f'{N}x{B}'] = e16
+    print(json.dumps(out))
 
 
 @pytest.mark.parametrize('kind', ['gan', 'gz'])
@@ -159,3 +211,7 @@ def test_full_size_properties(kind):
     for dy, dx in ((1, 0), (0, 3), (5, 7), (37, 61)):
         ys = gen.cnn_forward(torch.roll(x, shifts=(dy, dx), dims=(2, 3)))
         assert torch.equal(ys, torch.roll(y, shifts=(dy, dx), dims=(2, 3))), (dy, dx)
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'ab-child':
+    _ab_child()
