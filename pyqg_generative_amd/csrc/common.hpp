@@ -83,6 +83,7 @@ struct qgx_model {
     double2 *ph = nullptr, *dqh = nullptr; // dqh: spectral forcing of the last step (pyqg m.dqh)
     double2 *dq[3] = {nullptr, nullptr, nullptr};
     double2 *zbuf = nullptr;               // large-N path: (B,3,N,N) complex work array
+    bool q_stale = false;                  // large-N path: q lags qh (unparameterized steps keep no real-space q)
     int cur_q = 0;
     int i_new = 0, i_p = 1, i_pp = 2;      // roles of dq[]
     void *z = nullptr;                     // latent noise (B,2,N,N) float or double

@@ -4,7 +4,7 @@
 // digit-reversed order out.  Inverse = the transposed flow graph
 // (decimation-in-time, conjugate twiddles), digit-reversed in -> natural out.
 // Spectral-space code addresses coefficients through SpecDev::pos[], so no
-// reordering pass is ever executed.  Radices 2, 3, 4, 6, 8, 12.
+// reordering pass is ever executed.  Radices 2, 3, 4, 6, 8, 12, 16.
 //
 // A "line" is one 1-D transform of length N living in LDS at
 //   base + line * line_stride + e * elem_stride      (units: double2)
@@ -66,6 +66,33 @@ __device__ __forceinline__ void small_dft(double2 (&v)[R]) {
         v[1] = cadd(e[1], t1);   v[5] = csub(e[1], t1);
         v[2] = cadd(e[2], t2);   v[6] = csub(e[2], t2);
         v[3] = cadd(e[3], t3);   v[7] = csub(e[3], t3);
+    } else if constexpr (R == 16) {
+        // 16 = 4 x 4, decimation in time over the four interleaved length-4 sequences x[4m + r]:
+        // F_r = DFT4; G_r[k1] = W16^(r k1) F_r[k1]; X[k1 + 4 k2] = DFT4 over r of G_r[k1]
+        double2 f0[4] = {v[0], v[4], v[8], v[12]}, f1[4] = {v[1], v[5], v[9], v[13]};
+        double2 f2[4] = {v[2], v[6], v[10], v[14]}, f3[4] = {v[3], v[7], v[11], v[15]};
+        small_dft<4, FWD>(f0);
+        small_dft<4, FWD>(f1);
+        small_dft<4, FWD>(f2);
+        small_dft<4, FWD>(f3);
+        const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+        const double sg = FWD ? -1.0 : 1.0;
+        // W16^j = (cos(pi j / 8), sg sin(pi j / 8))
+        f1[1] = cmul(f1[1], make_double2(c1, sg * s1));                         // W^1
+        f1[2] = cmul(f1[2], make_double2(h, sg * h));                           // W^2
+        f1[3] = cmul(f1[3], make_double2(s1, sg * c1));                         // W^3
+        f2[1] = cmul(f2[1], make_double2(h, sg * h));                           // W^2
+        f2[2] = FWD ? mul_mi(f2[2]) : mul_pi(f2[2]);                            // W^4
+        f2[3] = cmul(f2[3], make_double2(-h, sg * h));                          // W^6
+        f3[1] = cmul(f3[1], make_double2(s1, sg * c1));                         // W^3
+        f3[2] = cmul(f3[2], make_double2(-h, sg * h));                          // W^6
+        f3[3] = cmul(f3[3], make_double2(-c1, -sg * s1));                       // W^9 = -W^1
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) {
+            double2 g[4] = {f0[k1], f1[k1], f2[k1], f3[k1]};
+            small_dft<4, FWD>(g);
+            v[k1] = g[0]; v[k1 + 4] = g[1]; v[k1 + 8] = g[2]; v[k1 + 12] = g[3];
+        }
     } else if constexpr (R == 6) {
         // 6 = 2 x 3, decimation in time: E = DFT3(even), O = DFT3(odd); X[k] = E[k] + W6^k O[k], X[k+3] = E[k] - W6^k O[k]
         double2 e[3] = {v[0], v[2], v[4]}, o[3] = {v[1], v[3], v[5]};
@@ -153,6 +180,7 @@ template <bool FWD>
 __device__ __forceinline__ void fft_pass_any(int R, double2 *Z, int nl, int ls, int es, int n, int N,
                                              const double2 *__restrict__ tw) {
     if (R == 8) fft_pass<8, FWD>(Z, nl, ls, es, n, N, tw);
+    else if (R == 16) fft_pass<16, FWD>(Z, nl, ls, es, n, N, tw);
     else if (R == 12) fft_pass<12, FWD>(Z, nl, ls, es, n, N, tw);
     else if (R == 6) fft_pass<6, FWD>(Z, nl, ls, es, n, N, tw);
     else if (R == 4) fft_pass<4, FWD>(Z, nl, ls, es, n, N, tw);
@@ -184,8 +212,10 @@ __device__ __forceinline__ void fft_lines_inv(double2 *Z, int nl, int ls, int es
 // every size a constant so that the index arithmetic of the passes folds to shifts and multiplies
 // (radix 12 = 4 x 3 and 6 = 2 x 3 finish 96 = 8 x 12 and 48 = 8 x 6 in two passes instead of three; the passes
 // are LDS-bandwidth bound, so a pass less is a third of the transform time less)
+// (radix 16 only on the large grids — n >= 128, and the 16 left over by it: 256 = 16 x 16, 128 = 16 x 8 in two
+// passes instead of three; the LDS-resident small grids keep their tuned plans)
 constexpr int pick_radix(int n) {
-    return n % 8 == 0 ? 8 : (n % 12 == 0 ? 12 : ((n % 6 == 0 && n % 4 != 0) ? 6 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : 3))));
+    return (n % 16 == 0 && (n >= 128 || n == 16)) ? 16 : n % 8 == 0 ? 8 : (n % 12 == 0 ? 12 : ((n % 6 == 0 && n % 4 != 0) ? 6 : (n % 4 == 0 ? 4 : (n % 2 == 0 ? 2 : 3))));
 }
 
 template <int N, int n>

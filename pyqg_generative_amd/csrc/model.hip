@@ -31,6 +31,8 @@ int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st);
 int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st);
 int large_invert(qgx_model *m, hipStream_t st);
 int large_step(qgx_model *m, const StepArgs &a, hipStream_t st);
+int large_ensure_q(qgx_model *m, hipStream_t st);
+int large_zpad();
 
 // One _step_forward: AB3 coefficient schedule of kernel.pyx::_forward_timestep, history rotation.
 static int model_step_once(qgx_model *m, bool has_S, const double *S, double weight, int demean, int diag,
@@ -239,7 +241,7 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
     m->small = small_path_fits(N);
     if (m->small) rc = small_prepare(d);
     else {
-        rc = dalloc(m->zbuf, (size_t)B * 3 * N * N);   // 3 complex work fields per member (spectral_large.hip ZF)
+        rc = dalloc(m->zbuf, (size_t)B * 3 * (N + large_zpad()) * N);   // 3 complex work fields per member (spectral_large.hip ZF), padded rows
         if (!rc) rc = large_prepare(d);
     }
     if (rc) { qgx_destroy(m); return rc; }
@@ -277,6 +279,7 @@ extern "C" int qgx_get(qgx_model *m, int field, void *out_dev, void *stream) {
     if (field == QGX_F_P)      // pyqg's derived field p = ifft(ph) (model.py::_calc_derived_fields), straight into the caller's buffer
         return m->small ? small_qh_to_q(m->d, m->ph, (double *)out_dev, (hipStream_t)stream)
                         : large_qh_to_q(m, m->ph, (double *)out_dev, (hipStream_t)stream);
+    if (field == QGX_F_Q && !m->small) { int rc = large_ensure_q(m, (hipStream_t)stream); if (rc) return rc; }
     const void *src = nullptr;
     switch (field) {
         case QGX_F_Q: src = m->q; break;
@@ -315,6 +318,7 @@ extern "C" int qgx_set_q(qgx_model *m, const double *q_dev, void *stream) {
     QGX_REQUIRE(m && q_dev, "qgx_set_q: null argument");
     hipStream_t st = (hipStream_t)stream;
     QGX_HIP(hipMemcpyAsync(m->q, q_dev, qgx_field_bytes(m, QGX_F_Q), hipMemcpyDeviceToDevice, st));
+    m->q_stale = false;
     return m->small ? small_q_to_qh(m->d, m->q, m->qh[m->cur_q], st) : large_q_to_qh(m, m->q, m->qh[m->cur_q], st);
 }
 
@@ -322,6 +326,7 @@ extern "C" int qgx_set_qh(qgx_model *m, const double *qh_dev, void *stream) {
     QGX_REQUIRE(m && qh_dev, "qgx_set_qh: null argument");
     hipStream_t st = (hipStream_t)stream;
     QGX_HIP(hipMemcpyAsync(m->qh[m->cur_q], qh_dev, qgx_field_bytes(m, QGX_F_QH), hipMemcpyDeviceToDevice, st));
+    m->q_stale = false;
     return m->small ? small_qh_to_q(m->d, m->qh[m->cur_q], m->q, st) : large_qh_to_q(m, m->qh[m->cur_q], m->q, st);
 }
 
@@ -394,6 +399,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
                 m->have_noise = true;
             }
             if (compute) {
+                if (!m->small) { int qrc = large_ensure_q(m, st); if (qrc) return qrc; }
                 // a redraw always comes with a recompute; the sampler update rides in the input kernel
                 int rc = generator_forward(p->gen, m->q, m->z, m->S, B, N, p->demean, st, draw ? &nu : nullptr);
                 if (rc) return rc;

@@ -27,7 +27,8 @@ __global__ void k_lines_fft(SpecDev d, double2 *base, int k0, int nfpm, int LPB)
     double2 *L = reinterpret_cast<double2 *>(lg_smem);
     const int N = d.N, LD = N + 1;
     int *pos = reinterpret_cast<int *>(L + (size_t)LPB * LD);
-    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));      // twiddle table in LDS, see lines_lds()
+    for (int t = threadIdx.x; t < N; t += blockDim.x) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
     const int groups = N / LPB;
     const int f = blockIdx.x / groups;
     const int l0 = (blockIdx.x - f * groups) * LPB;
@@ -42,8 +43,8 @@ __global__ void k_lines_fft(SpecDev d, double2 *base, int k0, int nfpm, int LPB)
         L[l * LD + (FWD ? e : pos[e])] = g[go];
     }
     __syncthreads();
-    if (FWD) fft_lines_fwd(L, LPB, LD, 1, N, d.nrad, d.rad, d.tw);
-    else fft_lines_inv(L, LPB, LD, 1, N, d.nrad, d.rad, d.tw);
+    if (FWD) fft_lines_fwd(L, LPB, LD, 1, N, d.nrad, d.rad, twl);
+    else fft_lines_inv(L, LPB, LD, 1, N, d.nrad, d.rad, twl);
     for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
         int l, e;
         size_t go;
@@ -207,19 +208,31 @@ __device__ __forceinline__ int pair_row(int p, int which, int N) {      // p in 
 
 // MODE 0: lines = (row, layer k): spectrum of (u_k + i v_k)/N^2 built from qh, inverse FFT along x -> zbuf[b][k]
 // MODE 1: lines = rows of the pair (A,B) = (src[b][0], src[b][1]) -> zbuf[b][2]
-template <int MODE>
-__global__ void k_l_rows_build_inv(SpecDev d, const double2 *src, double2 *zbuf, double2 *ph_out, int PPW) {
-    constexpr int NF = MODE == 0 ? 2 : 1;
+// MODE 3: MODE 0 and MODE 1 of the same qh in one pass (three lines per row): the unparameterized step derives
+//         q = irfft2(qh) beside (u, v) instead of keeping a real-space copy of q between steps
+// NN > 0: grid size, pairs per workgroup (PPWT) and thread count (NT) are compile-time constants: the index arithmetic
+// folds, the FFT plan is unrolled and — above all — the staging loops unroll, so that all of a thread's global loads
+// are in flight together (with run-time trip counts each thread waits for one 16-byte load at a time: 60-70 % of the
+// wave cycles were waits).
+template <int MODE, int NN = 0, int PPWT = 0, int NT = 0>
+__global__ __launch_bounds__(NT > 0 ? NT : 1024) void k_l_rows_build_inv(SpecDev d, const double2 *src, double2 *zbuf,
+                                                                         double2 *ph_out, int PPW_, int ZP) {
+    constexpr int NF = MODE == 0 ? 2 : (MODE == 3 ? 3 : 1);
+    constexpr bool CT = NN > 0;
     double2 *L = reinterpret_cast<double2 *>(lg_smem);
-    const int N = d.N, NK = d.NK, LD = N + 1, sz = N * NK;
+    const int N = CT ? NN : d.N, NK = N / 2 + 1, LD = N + 1, sz = N * NK;
+    const int PPW = CT ? PPWT : PPW_;
+    const int nthr = CT ? NT : (int)blockDim.x;
     const int nlines = PPW * 2 * NF;
     int *pos = reinterpret_cast<int *>(L + (size_t)nlines * LD);
-    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));      // twiddle table in LDS, see lines_lds()
+    for (int t = threadIdx.x; t < N; t += nthr) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
     const int groups = (N / 2) / PPW;
     const int b = blockIdx.x / groups, p0 = (blockIdx.x - b * groups) * PPW;
     const double2 *s0 = src + (size_t)b * 2 * sz, *s1 = s0 + sz;
     __syncthreads();
-    for (int t = threadIdx.x; t < PPW * 2 * NK; t += blockDim.x) {
+#pragma unroll
+    for (int t = threadIdx.x; t < PPW * 2 * NK; t += nthr) {
         const int i = t % NK, r = t / NK;                 // r = local row: pair r>>1, member r&1
         const int j = pair_row(p0 + (r >> 1), r & 1, N), jm = neg_mod_l(j, N);
         const int rm = (p0 + (r >> 1)) == 0 ? r : (r ^ 1);   // local row holding row -j
@@ -228,7 +241,7 @@ __global__ void k_l_rows_build_inv(SpecDev d, const double2 *src, double2 *zbuf,
         const double2 q0 = s0[idx], q1 = s1[idx];
         double2 q0m = q0, q1m = q1;
         if (selfc) { q0m = s0[idm]; q1m = s1[idm]; }
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 0 || MODE == 3) {
             const double kx = d.kk[i], ly = d.ll[j], lm = d.ll[jm];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -246,23 +259,27 @@ __global__ void k_l_rows_build_inv(SpecDev d, const double2 *src, double2 *zbuf,
                 L[(r * NF + k) * LD + pos[i]] = make_double2((uh.x - vh.y) * d.invN2, (uh.y + vh.x) * d.invN2);
                 if (!selfc) L[(rm * NF + k) * LD + pos[N - i]] = make_double2((uh.x + vh.y) * d.invN2, (vh.x - uh.y) * d.invN2);
             }
-        } else {
+        }
+        if constexpr (MODE == 1 || MODE == 3) {
+            constexpr int KQ = MODE == 3 ? 2 : 0;
             double2 a = q0, bb = q1;
             if (selfc) {
                 a = make_double2(0.5 * (a.x + q0m.x), 0.5 * (a.y - q0m.y));
                 bb = make_double2(0.5 * (bb.x + q1m.x), 0.5 * (bb.y - q1m.y));
             }
-            L[r * LD + pos[i]] = make_double2((a.x - bb.y) * d.invN2, (a.y + bb.x) * d.invN2);
-            if (!selfc) L[rm * LD + pos[N - i]] = make_double2((a.x + bb.y) * d.invN2, (bb.x - a.y) * d.invN2);
+            L[(r * NF + KQ) * LD + pos[i]] = make_double2((a.x - bb.y) * d.invN2, (a.y + bb.x) * d.invN2);
+            if (!selfc) L[(rm * NF + KQ) * LD + pos[N - i]] = make_double2((a.x + bb.y) * d.invN2, (bb.x - a.y) * d.invN2);
         }
     }
     __syncthreads();
-    fft_lines_inv(L, nlines, LD, 1, N, d.nrad, d.rad, d.tw);
-    for (int t = threadIdx.x; t < nlines * N; t += blockDim.x) {
+    if constexpr (CT) fft_lines_inv_t<NN, NN>(L, nlines, LD, 1, twl);
+    else fft_lines_inv(L, nlines, LD, 1, N, d.nrad, d.rad, twl);
+#pragma unroll
+    for (int t = threadIdx.x; t < nlines * N; t += nthr) {
         const int e = t % N, line = t / N;
         const int r = line / NF, k = line - r * NF;
         const int j = pair_row(p0 + (r >> 1), r & 1, N);
-        zbuf[((size_t)b * ZF + (MODE == 0 ? k : 2)) * N * N + (size_t)j * N + e] = L[line * LD + e];
+        zbuf[((size_t)b * ZF + (MODE == 1 ? 2 : k)) * ZP * N + (size_t)j * ZP + e] = L[line * LD + e];
     }
 }
 
@@ -271,7 +288,8 @@ __global__ void k_l_rows_S(SpecDev d, const double *S, double2 *zbuf, double w, 
     double2 *L = reinterpret_cast<double2 *>(lg_smem);
     const int N = d.N, LD = N + 1, rz = N * N;
     int *pos = reinterpret_cast<int *>(L + (size_t)LPB * LD);
-    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));      // twiddle table in LDS, see lines_lds()
+    for (int t = threadIdx.x; t < N; t += blockDim.x) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
     const int groups = N / LPB;
     const int b = blockIdx.x / groups, j0 = (blockIdx.x - b * groups) * LPB;
     const double *S0 = S + (size_t)b * 2 * rz, *S1 = S0 + rz;
@@ -281,7 +299,7 @@ __global__ void k_l_rows_S(SpecDev d, const double *S, double2 *zbuf, double w, 
         L[l * LD + e] = make_double2(w * S0[o], w * S1[o]);
     }
     __syncthreads();
-    fft_lines_fwd(L, LPB, LD, 1, N, d.nrad, d.rad, d.tw);
+    fft_lines_fwd(L, LPB, LD, 1, N, d.nrad, d.rad, twl);
     double2 *g = zbuf + ((size_t)b * ZF + 2) * N * N;
     for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
         const int e = t % N, l = t / N;
@@ -297,7 +315,8 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
     double2 *L = reinterpret_cast<double2 *>(lg_smem);
     const int N = d.N, LD = N + 1, rz = N * N;
     int *pos = reinterpret_cast<int *>(L + (size_t)CPB * LD);
-    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));      // twiddle table in LDS, see lines_lds()
+    for (int t = threadIdx.x; t < N; t += blockDim.x) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
     const int groups = N / CPB;
     const int nf = MODE == 0 ? 2 : 1;
     const int f = blockIdx.x / groups, c0 = (blockIdx.x - f * groups) * CPB;
@@ -310,9 +329,9 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
     }
     __syncthreads();
     if constexpr (MODE == 1) {
-        fft_lines_fwd(L, CPB, LD, 1, N, d.nrad, d.rad, d.tw);
+        fft_lines_fwd(L, CPB, LD, 1, N, d.nrad, d.rad, twl);
     } else {
-        fft_lines_inv(L, CPB, LD, 1, N, d.nrad, d.rad, d.tw);
+        fft_lines_inv(L, CPB, LD, 1, N, d.nrad, d.rad, twl);
     }
     if constexpr (MODE == 0) {
         const double Uk = d.U[k];
@@ -326,7 +345,7 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
             L[c * LD + r] = make_double2((uv.x + Uk) * qv, uv.y * qv);
         }
         __syncthreads();
-        fft_lines_fwd(L, CPB, LD, 1, N, d.nrad, d.rad, d.tw);
+        fft_lines_fwd(L, CPB, LD, 1, N, d.nrad, d.rad, twl);
     }
     if constexpr (MODE == 2) {
         double *q0 = q + (size_t)b * 2 * rz, *q1 = q0 + rz;
@@ -344,27 +363,86 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
     }
 }
 
+// column tiles of all three work fields of a member (after k_l_rows_build_inv<3>): inverse along y of
+// (u_1 + i v_1), (u_2 + i v_2) and (q_1 + i q_2); the advection products with q taken from LDS; forward along y of
+// the two product fields -> zbuf[b][0..1].  No real-space q is read or written.
+template <int NN = 0, int CPBT = 0, int NT = 0>
+__global__ __launch_bounds__(NT > 0 ? NT : 1024) void k_l_cols3(SpecDev d, double2 *zbuf, double *u, double *v, int CPB_, int ZP) {
+    constexpr bool CT = NN > 0;
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    const int N = CT ? NN : d.N, LD = N + 1, rz = N * N;
+    const int CPB = CT ? CPBT : CPB_;
+    const int nthr = CT ? NT : (int)blockDim.x;
+    int *pos = reinterpret_cast<int *>(L + (size_t)3 * CPB * LD);
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));      // twiddle table in LDS, see lines_lds()
+    for (int t = threadIdx.x; t < N; t += nthr) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
+    const int groups = N / CPB;
+    const int b = blockIdx.x / groups, c0 = (blockIdx.x - b * groups) * CPB;
+    const size_t fz = (size_t)ZP * N;                    // one work field, rows at pitch ZP (see large_step)
+    double2 *g = zbuf + (size_t)b * ZF * fz;
+    __syncthreads();
+#pragma unroll
+    for (int t = threadIdx.x; t < 3 * CPB * N; t += nthr) {
+        const int k = t / (CPB * N), t2 = t - k * CPB * N;
+        const int r = t2 / CPB, c = t2 - r * CPB;
+        L[(k * CPB + c) * LD + pos[r]] = g[(size_t)k * fz + (size_t)r * ZP + c0 + c];
+    }
+    __syncthreads();
+    if constexpr (CT) fft_lines_inv_t<NN, NN>(L, 3 * CPB, LD, 1, twl);
+    else fft_lines_inv(L, 3 * CPB, LD, 1, N, d.nrad, d.rad, twl);
+#pragma unroll
+    for (int t = threadIdx.x; t < 2 * CPB * N; t += nthr) {
+        const int k = t / (CPB * N), t2 = t - k * CPB * N;
+        const int r = t2 / CPB, c = t2 - r * CPB;
+        const double2 uv = L[(k * CPB + c) * LD + r];
+        const double2 qq = L[(2 * CPB + c) * LD + r];
+        const double qv = k == 0 ? qq.x : qq.y;
+        if (u) {
+            const size_t o = (size_t)b * 2 * rz + (size_t)k * rz + (size_t)r * N + c0 + c;
+            u[o] = uv.x; v[o] = uv.y;
+        }
+        L[(k * CPB + c) * LD + r] = make_double2((uv.x + d.U[k]) * qv, uv.y * qv);
+    }
+    __syncthreads();
+    if constexpr (CT) fft_lines_fwd_t<NN, NN>(L, 2 * CPB, LD, 1, twl);
+    else fft_lines_fwd(L, 2 * CPB, LD, 1, N, d.nrad, d.rad, twl);
+#pragma unroll
+    for (int t = threadIdx.x; t < 2 * CPB * N; t += nthr) {
+        const int k = t / (CPB * N), t2 = t - k * CPB * N;
+        const int r = t2 / CPB, c = t2 - r * CPB;
+        g[(size_t)k * fz + (size_t)r * ZP + c0 + c] = L[(k * CPB + c) * LD + pos[r]];
+    }
+}
+
 // rows of zbuf[b][0..1] (pairs j, -j): forward FFT along x, unpack (uq_k, vq_k), tendency + friction + forcing,
 // AB3 + filter -> dq_new, qh_out.  The forcing spectrum is read from zbuf[b][2] (already transformed).
-__global__ void k_l_rows_fwd_tend(SpecDev d, StepArgs a, const double2 *zbuf, int PPW) {
+template <int NN = 0, int PPWT = 0, int NT = 0>
+__global__ __launch_bounds__(NT > 0 ? NT : 1024) void k_l_rows_fwd_tend(SpecDev d, StepArgs a, const double2 *zbuf, int PPW_, int ZP) {
+    constexpr bool CT = NN > 0;
     double2 *L = reinterpret_cast<double2 *>(lg_smem);
-    const int N = d.N, NK = d.NK, LD = N + 1, sz = N * NK;
+    const int N = CT ? NN : d.N, NK = N / 2 + 1, LD = N + 1, sz = N * NK;
+    const int PPW = CT ? PPWT : PPW_;
+    const int nthr = CT ? NT : (int)blockDim.x;
     const int nlines = PPW * 4;
     int *pos = reinterpret_cast<int *>(L + (size_t)nlines * LD);
-    for (int t = threadIdx.x; t < N; t += blockDim.x) pos[t] = d.pos[t];
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));      // twiddle table in LDS, see lines_lds()
+    for (int t = threadIdx.x; t < N; t += nthr) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
     const int groups = (N / 2) / PPW;
     const int b = blockIdx.x / groups, p0 = (blockIdx.x - b * groups) * PPW;
-    for (int t = threadIdx.x; t < nlines * N; t += blockDim.x) {
+#pragma unroll
+    for (int t = threadIdx.x; t < nlines * N; t += nthr) {
         const int e = t % N, line = t / N;
         const int r = line >> 1, k = line & 1;
         const int j = pair_row(p0 + (r >> 1), r & 1, N);
-        L[line * LD + e] = zbuf[((size_t)b * ZF + k) * N * N + (size_t)j * N + e];
+        L[line * LD + e] = zbuf[((size_t)b * ZF + k) * ZP * N + (size_t)j * ZP + e];
     }
     __syncthreads();
-    fft_lines_fwd(L, nlines, LD, 1, N, d.nrad, d.rad, d.tw);
+    if constexpr (CT) fft_lines_fwd_t<NN, NN>(L, nlines, LD, 1, twl);
+    else fft_lines_fwd(L, nlines, LD, 1, N, d.nrad, d.rad, twl);
     const double2 *qh0 = a.qh_in + (size_t)b * 2 * sz, *qh1 = qh0 + sz;
-    const double2 *ZS = zbuf + ((size_t)b * ZF + 2) * N * N;
-    for (int t = threadIdx.x; t < PPW * 2 * NK; t += blockDim.x) {
+    const double2 *ZS = zbuf + ((size_t)b * ZF + 2) * ZP * N;
+#pragma unroll
+    for (int t = threadIdx.x; t < PPW * 2 * NK; t += nthr) {
         const int i = t % NK, r = t / NK;
         const int j = pair_row(p0 + (r >> 1), r & 1, N), jm = neg_mod_l(j, N), im = neg_mod_l(i, N);
         const int rm = (p0 + (r >> 1)) == 0 ? r : (r ^ 1);
@@ -373,7 +451,7 @@ __global__ void k_l_rows_fwd_tend(SpecDev d, StepArgs a, const double2 *zbuf, in
         const double kx = d.kk[i], ly = d.ll[j];
         double2 s0 = make_double2(0., 0.), s1 = s0;
         if (a.has_S) {
-            const double2 A = ZS[(size_t)j * N + i], C = ZS[(size_t)jm * N + im];
+            const double2 A = ZS[(size_t)j * ZP + i], C = ZS[(size_t)jm * ZP + im];
             s0 = make_double2(0.5 * (A.x + C.x), 0.5 * (A.y - C.y));
             s1 = make_double2(0.5 * (A.y + C.y), -0.5 * (A.x - C.x));
             if (a.demean && idx == 0) { s0 = make_double2(0., 0.); s1 = s0; }
@@ -413,21 +491,61 @@ static int lines_per_block(int N) {
     int lpb = 64;
     // <= 36 KB of LDS per workgroup: 4 workgroups per CU hide the global-memory latency of these
     // short kernels better than longer lines do (256x256, B=64: 360 us/step at 8 lines vs 456 at 16)
-    while (lpb > 1 && ((size_t)lpb * (N + 1) * 16 + (size_t)N * 4 > 36 * 1024 || N % lpb)) lpb /= 2;
+    while (lpb > 1 && ((size_t)lpb * (N + 1) * 16 + (size_t)N * 20 > 40 * 1024 || N % lpb)) lpb /= 2;
     return lpb;
 }
-static size_t lines_lds(int N, int lpb) { return (((size_t)lpb * (N + 1) * 16 + (size_t)N * 4) + 15) & ~(size_t)15; }
+// LDS of a line kernel: the lines (row stride N + 1), the digit-reversal table and the twiddle table (twiddles read
+// from global memory put an L2 round trip into every butterfly of every pass: the kernels were 60-70 % wait)
+static size_t lines_lds(int N, int lpb) { return (size_t)lpb * (N + 1) * 16 + (size_t)((N + 3) & ~3) * 4 + (size_t)N * 16; }
+
+// tile shapes of the three-field kernels of the unparameterized step: columns per tile of k_l_cols3 (3 lines per
+// column) and mirror pairs of rows per workgroup of k_l_rows_build_inv<3> (6 lines per pair)
+static int cols3_cpb(int N) {
+    static const int forced = getenv("QGX_LARGE_C3") ? atoi(getenv("QGX_LARGE_C3")) : 0;       // tuning aid
+    int c = forced > 0 ? forced : 4;
+    while (c > 1 && (N % c || lines_lds(N, 3 * c) > 160 * 1024 - 512)) c /= 2;
+    return (N % c == 0 && lines_lds(N, 3 * c) <= 160 * 1024 - 512) ? c : 0;
+}
+static int rows3_ppw(int N) {
+    static const int forced = getenv("QGX_LARGE_P3") ? atoi(getenv("QGX_LARGE_P3")) : 0;
+    const int p = forced > 0 ? forced : 1;
+    return ((N / 2) % p == 0 && lines_lds(N, 6 * p) <= 160 * 1024 - 512) ? p : 1;
+}
+
+// Row pitch of the work fields between the row and the column kernels of the lazy path, in complex elements beyond N.
+// A column tile touches N rows at one x offset: with the natural pitch (N * 16 B = 4 KiB at 256) every one of those
+// accesses lands on the same few memory channels.
+int large_zpad() {
+    static const int pad = getenv("QGX_LARGE_ZPAD") ? atoi(getenv("QGX_LARGE_ZPAD")) : 8;
+    return pad < 0 ? 0 : pad;
+}
 
 int large_prepare(const SpecDev &d) {
-    const int bytes = (int)lines_lds(d.N, lines_per_block(d.N));
-    QGX_HIP(hipFuncSetAttribute((const void *)k_lines_fft<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QGX_HIP(hipFuncSetAttribute((const void *)k_lines_fft<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QGX_HIP(hipFuncSetAttribute((const void *)k_lines_fft<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    QGX_HIP(hipFuncSetAttribute((const void *)k_lines_fft<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    const void *fused[] = {(const void *)k_l_rows_build_inv<0>, (const void *)k_l_rows_build_inv<1>, (const void *)k_l_rows_S,
-                           (const void *)k_l_cols<0>, (const void *)k_l_cols<1>, (const void *)k_l_cols<2>,
-                           (const void *)k_l_rows_fwd_tend};
-    for (const void *f : fused) QGX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    // the attribute is a per-kernel cap shared by every model of the process (models of different N coexist:
+    // hires run + coarse-grained forcing models), so it is set once to the most any grid may ask for
+    (void)d;
+    const int cap = 160 * 1024 - 512;
+    const void *kernels[] = {(const void *)k_lines_fft<true, false>, (const void *)k_lines_fft<true, true>,
+                             (const void *)k_lines_fft<false, false>, (const void *)k_lines_fft<false, true>,
+                             (const void *)k_l_rows_build_inv<0>, (const void *)k_l_rows_build_inv<1>,
+                             (const void *)k_l_rows_build_inv<3>, (const void *)k_l_rows_S, (const void *)k_l_cols<0>,
+                             (const void *)k_l_cols<1>, (const void *)k_l_cols<2>, (const void *)k_l_cols3<>,
+                             (const void *)k_l_rows_fwd_tend<>,
+#define QGX_L3(NN, P1, T1, C2, T2, P3, T3) (const void *)k_l_rows_build_inv<3, NN, P1, T1>, \
+                   (const void *)k_l_cols3<NN, C2, T2>, (const void *)k_l_rows_fwd_tend<NN, P3, T3>
+                             QGX_L3(128, 2, 512, 8, 1024, 4, 512), QGX_L3(256, 2, 512, 8, 1024, 4, 512),
+                             QGX_L3(512, 1, 256, 4, 512, 2, 256),
+#ifdef QGX_L3_SWEEP
+                             (const void *)k_l_cols3<256, 8, 512>, (const void *)k_l_cols3<256, 8, 1024>, (const void *)k_l_cols3<256, 4, 512>,
+                             (const void *)k_l_cols3<256, 4, 128>, (const void *)k_l_cols3<256, 2, 128>, (const void *)k_l_cols3<256, 2, 256>,
+                             (const void *)k_l_rows_build_inv<3, 256, 2, 512>, (const void *)k_l_rows_build_inv<3, 256, 2, 256>,
+                             (const void *)k_l_rows_build_inv<3, 256, 1, 128>, (const void *)k_l_rows_fwd_tend<256, 4, 512>,
+                             (const void *)k_l_rows_fwd_tend<256, 4, 256>, (const void *)k_l_rows_fwd_tend<256, 2, 128>,
+                             (const void *)k_l_rows_fwd_tend<256, 1, 128>, (const void *)k_l_rows_fwd_tend<256, 1, 256>,
+#endif
+                             };
+#undef QGX_L3
+    for (const void *f : kernels) QGX_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
     return QGX_OK;
 }
 
@@ -503,6 +621,14 @@ static int large_step_unfused(qgx_model *m, const StepArgs &a, hipStream_t st) {
     return QGX_OK;
 }
 
+// m->q <- irfft2 of the current qh if the lazy unparameterized path left it behind
+int large_ensure_q(qgx_model *m, hipStream_t st) {
+    if (!m->q_stale) return QGX_OK;
+    int rc = large_qh_to_q(m, m->qh[m->cur_q], m->q, st);
+    if (!rc) m->q_stale = false;
+    return rc;
+}
+
 int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
     static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
     const SpecDev &d = m->d;
@@ -510,19 +636,80 @@ int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
     if (unfused || lpb < 4 || (d.N / 2) % (lpb / 4)) return large_step_unfused(m, a, st);
     const size_t lds = lines_lds(d.N, lpb);
     const int B = d.B, N = d.N;
+    // Unparameterized steps (the 256 x 256 forcing-dataset runs) keep NO real-space q between steps: q = irfft2(qh)
+    // rides as a third field through the two kernels that transform (u, v) — 3 launches per step instead of 5, no q
+    // write + read, no second read of qh_out; m->q is refreshed on demand (large_ensure_q: snapshots, generator).
+    static const bool eager = getenv("QGX_LARGE_EAGER_Q") != nullptr;        // A/B aid
+    const int c3 = cols3_cpb(N), ppw = rows3_ppw(N);
+    const int zp = N + large_zpad();
+    if (!a.has_S && !eager && c3 > 0) {
+        const size_t lds1 = lines_lds(N, 6 * ppw), lds2 = lines_lds(N, 3 * c3);
+        static const bool generic = getenv("QGX_LARGE_GENERIC") != nullptr;   // A/B aid: run-time-N kernels
+        double2 *const ph_o = a.diag ? a.ph : (double2 *)nullptr;
+        double *const u_o = a.diag ? a.u : (double *)nullptr, *const v_o = a.diag ? a.v : (double *)nullptr;
+        // compile-time specialisations; tiles (mirror pairs of rows / columns / pairs per workgroup) and thread counts
+        // from a sweep at 256 x 256, 64 members (bench_tools/large_sweep.sh with a -DQGX_L3_SWEEP build)
+#define QGX_L3(NN, P1, T1, C2, T2, P3, T3)                                                                             \
+    {                                                                                                                 \
+        hipLaunchKernelGGL((k_l_rows_build_inv<3, NN, P1, T1>), dim3(B * (NN / 2 / P1)), dim3(T1), lines_lds(NN, 6 * P1), \
+                           st, d, a.qh_in, m->zbuf, ph_o, P1, zp);                                                    \
+        hipLaunchKernelGGL((k_l_cols3<NN, C2, T2>), dim3(B * (NN / C2)), dim3(T2), lines_lds(NN, 3 * C2), st, d, m->zbuf, \
+                           u_o, v_o, C2, zp);                                                                         \
+        hipLaunchKernelGGL((k_l_rows_fwd_tend<NN, P3, T3>), dim3(B * (NN / 2 / P3)), dim3(T3), lines_lds(NN, 4 * P3), st, \
+                           d, a, (const double2 *)m->zbuf, P3, zp);                                                   \
+    }
+#ifdef QGX_L3_SWEEP      // tuning build: tile / thread variants of the 256 x 256 kernels, picked by environment variables
+        static const int v1 = getenv("QGX_V1") ? atoi(getenv("QGX_V1")) : 0, v2 = getenv("QGX_V2") ? atoi(getenv("QGX_V2")) : 0,
+                         v3 = getenv("QGX_V3") ? atoi(getenv("QGX_V3")) : 0;
+        if (!generic && N == 256 && (v1 || v2 || v3)) {
+#define QGX_K1(P, T) hipLaunchKernelGGL((k_l_rows_build_inv<3, 256, P, T>), dim3(B * (128 / P)), dim3(T), lines_lds(256, 6 * P), st, d, a.qh_in, m->zbuf, ph_o, P, zp)
+#define QGX_K2(C, T) hipLaunchKernelGGL((k_l_cols3<256, C, T>), dim3(B * (256 / C)), dim3(T), lines_lds(256, 3 * C), st, d, m->zbuf, u_o, v_o, C, zp)
+#define QGX_K3(P, T) hipLaunchKernelGGL((k_l_rows_fwd_tend<256, P, T>), dim3(B * (128 / P)), dim3(T), lines_lds(256, 4 * P), st, d, a, (const double2 *)m->zbuf, P, zp)
+            if (v1 == 1) QGX_K1(2, 512); else if (v1 == 2) QGX_K1(2, 256); else if (v1 == 3) QGX_K1(1, 128); else QGX_K1(1, 256);
+            if (v2 == 1) QGX_K2(8, 512); else if (v2 == 2) QGX_K2(8, 1024); else if (v2 == 3) QGX_K2(4, 512); else if (v2 == 4) QGX_K2(4, 128);
+            else if (v2 == 5) QGX_K2(2, 128); else if (v2 == 6) QGX_K2(2, 256); else QGX_K2(4, 256);
+            if (v3 == 1) QGX_K3(4, 512); else if (v3 == 2) QGX_K3(4, 256); else if (v3 == 3) QGX_K3(2, 128); else if (v3 == 4) QGX_K3(1, 128);
+            else if (v3 == 5) QGX_K3(1, 256); else QGX_K3(2, 256);
+        } else
+#endif
+        if (!generic && N == 256) QGX_L3(256, 2, 512, 8, 1024, 4, 512)
+        else if (!generic && N == 128) QGX_L3(128, 2, 512, 8, 1024, 4, 512)
+        else if (!generic && N == 512) QGX_L3(512, 1, 256, 4, 512, 2, 256)
+        else {
+            static const int t1 = getenv("QGX_LARGE_T1") ? atoi(getenv("QGX_LARGE_T1")) : 256;   // tuning aids: threads
+            static const int t2 = getenv("QGX_LARGE_T2") ? atoi(getenv("QGX_LARGE_T2")) : 256;
+            static const int t3 = getenv("QGX_LARGE_T3") ? atoi(getenv("QGX_LARGE_T3")) : 256;
+            static const int p4 = getenv("QGX_LARGE_P4") ? atoi(getenv("QGX_LARGE_P4")) : 0;     // row pairs of the tendency kernel
+            const int ppw4 = p4 > 0 && (N / 2) % p4 == 0 ? p4 : lpb / 4;
+            hipLaunchKernelGGL(k_l_rows_build_inv<3>, dim3(B * ((N / 2) / ppw)), dim3(t1), lds1, st, d, a.qh_in, m->zbuf,
+                               ph_o, ppw, zp);
+            hipLaunchKernelGGL(k_l_cols3<>, dim3(B * (N / c3)), dim3(t2), lds2, st, d, m->zbuf, u_o, v_o, c3, zp);
+            hipLaunchKernelGGL(k_l_rows_fwd_tend<>, dim3(B * ((N / 2) / ppw4)), dim3(t3), lines_lds(N, 4 * ppw4), st, d, a,
+                               (const double2 *)m->zbuf, ppw4, zp);
+        }
+#undef QGX_L3
+        QGX_HIP(hipGetLastError());
+        m->q_stale = true;
+        return QGX_OK;
+    }
+    if (m->q_stale) {            // the eager path reads q^n from memory
+        int rc = large_qh_to_q(m, a.qh_in, a.q, st);
+        if (rc) return rc;
+        m->q_stale = false;
+    }
     if (a.has_S) {
         hipLaunchKernelGGL(k_l_rows_S, dim3(B * (N / lpb)), dim3(256), lds, st, d, a.S, m->zbuf, a.weight, lpb);
         hipLaunchKernelGGL(k_l_cols<1>, dim3(B * (N / lpb)), dim3(256), lds, st, d, m->zbuf, (double *)nullptr,
                            (double *)nullptr, (double *)nullptr, lpb);
     }
     hipLaunchKernelGGL(k_l_rows_build_inv<0>, dim3(B * ((N / 2) / (lpb / 4))), dim3(256), lds, st, d, a.qh_in, m->zbuf,
-                       a.diag ? a.ph : (double2 *)nullptr, lpb / 4);
+                       a.diag ? a.ph : (double2 *)nullptr, lpb / 4, N);
     hipLaunchKernelGGL(k_l_cols<0>, dim3(B * 2 * (N / lpb)), dim3(256), lds, st, d, m->zbuf, a.q,
                        a.diag ? a.u : (double *)nullptr, a.diag ? a.v : (double *)nullptr, lpb);
-    hipLaunchKernelGGL(k_l_rows_fwd_tend, dim3(B * ((N / 2) / (lpb / 4))), dim3(256), lds, st, d, a,
-                       (const double2 *)m->zbuf, lpb / 4);
+    hipLaunchKernelGGL(k_l_rows_fwd_tend<>, dim3(B * ((N / 2) / (lpb / 4))), dim3(256), lds, st, d, a,
+                       (const double2 *)m->zbuf, lpb / 4, N);
     hipLaunchKernelGGL(k_l_rows_build_inv<1>, dim3(B * ((N / 2) / (lpb / 2))), dim3(256), lds, st, d,
-                       (const double2 *)a.qh_out, m->zbuf, (double2 *)nullptr, lpb / 2);
+                       (const double2 *)a.qh_out, m->zbuf, (double2 *)nullptr, lpb / 2, N);
     hipLaunchKernelGGL(k_l_cols<2>, dim3(B * (N / lpb)), dim3(256), lds, st, d, m->zbuf, a.q, (double *)nullptr,
                        (double *)nullptr, lpb);
     QGX_HIP(hipGetLastError());
