@@ -78,6 +78,13 @@ class Dev:
             e = cls.plan(N, 2, device)
             if name == 'filtr':
                 t = e.table(_lib.T_FILTR)
+            elif name == 'sharp':
+                # pyqg's exponential filter with filterfac = 1e20 (advect '2/3-rule', operators.py:253): a sharp
+                # cut at 0.65 pi; same expression as model.py::_initialize_filter
+                wvx = np.sqrt(e.table(_lib.T_WV2)) * (cls.L / N)
+                with np.errstate(under='ignore'):
+                    t = np.exp(-1e20 * (wvx - 0.65 * np.pi) ** 4.)
+                t[wvx <= 0.65 * np.pi] = 1.
             else:
                 _, ratio = name
                 t = np.exp(-e.table(_lib.T_WV2) * (ratio * cls.L / N) ** 2 / 24)
@@ -206,7 +213,8 @@ class Dev:
             return cls.divergence(cls.fft_interpolate(cls.mul(a, b), N, n),
                                   cls.fft_interpolate(cls.mul(a, c), N, n))
         if dealias == '2/3-rule':
-            raise NotImplementedError("'2/3-rule' dealiasing is used by no script of the reference")
+            a, b, c = (cls.spectral_filter(t, 'sharp') for t in (var, u, v))
+            return cls.spectral_filter(cls.divergence(cls.mul(a, b), cls.mul(a, c)), 'sharp')
         raise ValueError('dealias should be none or 2/3-rule or 3/2-rule')
 
     @classmethod
@@ -293,6 +301,13 @@ def apply_operator_to_model(q, nc, operator, pyqg_params):
     m.q = qf
     m._invert()
     return m
+
+
+def PV_subgrid_flux(q, nc, operator, pyqg_params):
+    """Subgrid PV fluxes (operators.py:269-281): (uq_flux, vq_flux) = filtered-model product minus filtered product."""
+    m = apply_operator_to_model(q, 1, lambda x, n: x, pyqg_params)
+    mf = apply_operator_to_model(q, nc, operator, pyqg_params)
+    return mf.u * mf.q - operator(m.u * m.q, nc), mf.v * mf.q - operator(m.v * m.q, nc)
 
 
 def PV_subgrid_forcing(q, nc, operator, pyqg_params, dealias='none'):

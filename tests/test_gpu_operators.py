@@ -57,9 +57,15 @@ def test_advect_and_subgrid_forcing_match_oracle():
     qh = m.fft(rs.randn(2, N, N) * np.array([8e-6, 1e-6])[:, None, None]) * (m.wv < 0.95 * m.kk[-1])
     m.set_qh(qh)
     m._invert()
-    for rule in ('none', '3/2-rule'):
+    for rule in ('none', '3/2-rule', '2/3-rule'):
         _close(op.advect(m.q, m.u, m.v, rule), ref.advect(m.q, m.u, m.v, rule), 1e-11)
     params = {}
+    # subgrid fluxes (operators.py:269-281)
+    uq, vq = op.PV_subgrid_flux(m.q, 64, op.Operator2, params)
+    mm0 = ref.apply_operator_to_model(m.q, 1, ref.identity_operator, params)
+    mf0 = ref.apply_operator_to_model(m.q, 64, ref.Operator2, params)
+    _close(uq, mf0.u * mf0.q - ref.Operator2(mm0.u * mm0.q, 64), 1e-10)
+    _close(vq, mf0.v * mf0.q - ref.Operator2(mm0.v * mm0.q, 64), 1e-10)
     for oper, roper in ((op.Operator2, ref.Operator2), (op.Operator5, ref.Operator5), (op.Operator1, ref.Operator1)):
         f, mf, mm = op.PV_subgrid_forcing(m.q, 64, oper, params, '3/2-rule')
         fr, mfr, mmr = ref.PV_subgrid_forcing(m.q, 64, roper, params, '3/2-rule')
