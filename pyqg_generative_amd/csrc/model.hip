@@ -130,10 +130,13 @@ __global__ void k_status(SpecDev d, const double2 *ph, const double *u, const do
 using namespace qgx;
 
 extern "C" const char *qgx_last_error(void) { return g_err; }
+#ifndef QGX_SOURCE_HASH
+#define QGX_SOURCE_HASH "unknown"
+#endif
 #ifdef QGX_AB
-extern "C" const char *qgx_version(void) { return "qgx 0.2 (gfx950) +ab"; }     // A/B library: every kernel variant
+extern "C" const char *qgx_version(void) { return "qgx 0.2 (gfx950) src " QGX_SOURCE_HASH " +ab"; }   // A/B library: every kernel variant
 #else
-extern "C" const char *qgx_version(void) { return "qgx 0.2 (gfx950)"; }
+extern "C" const char *qgx_version(void) { return "qgx 0.2 (gfx950) src " QGX_SOURCE_HASH; }
 #endif
 
 extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {

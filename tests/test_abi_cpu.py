@@ -29,6 +29,22 @@ def test_version_and_error_string_without_gpu():
     assert isinstance(_lib.lib.qgx_last_error(), bytes)
 
 
+def test_library_was_built_from_the_sources_in_the_tree():
+    """qgx_version() carries a fingerprint of csrc/*.hip, *.hpp and include/qgx.h taken at build time (Makefile SRC_HASH):
+    a stale prebuilt libqgx.so — the GPU box never rebuilds — fails here instead of passing old kernels off as new"""
+    import hashlib
+    from pyqg_generative_amd import _lib
+    csrc = os.path.join(ROOT, 'pyqg_generative_amd', 'csrc')
+    mk = open(os.path.join(csrc, 'Makefile')).read()
+    srcs = re.search(r'^SRCS\s*:=\s*(.*)$', mk, flags=re.M).group(1).split()
+    hdrs = re.search(r'^HDRS\s*:=\s*(.*)$', mk, flags=re.M).group(1).split()
+    h = hashlib.sha256()
+    for f in srcs + hdrs:
+        h.update(open(os.path.join(csrc, f), 'rb').read())
+    version = _lib.lib.qgx_version().decode()
+    assert f'src {h.hexdigest()[:16]}' in version, (version, h.hexdigest()[:16])
+
+
 def test_struct_sizes_match_header():
     from pyqg_generative_amd import _lib
     assert ctypes.sizeof(_lib.qgx_config) == 16 + 10 * 8
