@@ -349,3 +349,60 @@ def test_full_size_step_members_are_independent():
         for s in range(nsteps):
             m._step_forward()
         assert _rel(qh[b].cpu().numpy(), m.qh) < 5e-6
+
+
+@pytest.mark.parametrize('case', range(14))
+def test_randomised_configurations_match_oracle(case):
+    """seeded sweep over grid size x member count (odd counts, counts around the kernel-selection thresholds) x
+    generator kind x sampler: two online steps against the oracle, member 0, a middle member and the last member"""
+    import pyqg_generative_amd._lib as L
+    rs = np.random.RandomState(1000 + case)
+    N = [32, 48, 64, 96, 128, 64, 96, 48, 64, 32, 64, 96, 48, 128][case]
+    B = [1, 3, 5, 7, 2, 9, 13, 17, 33, 40, 6, 57, 11, 3][case]
+    kind = ['gan', 'vae', 'gz'][case % 3]
+    sampling, nd = [('AR1', 1), ('constant', 2), ('AR1', 4), ('constant', 1)][case % 4]
+    params = JET if case % 5 == 0 else dict(dt=dt_for(N))
+    nsteps = 2
+    q0 = _eddy_like_q(rs, B, N)
+    gen = _gpu_generator(kind)
+    ora = load_generator(kind)
+    e = _engine(N, B, **params)
+    e.set_q(q0)
+    shape = (B, 2, N, N) if kind == 'gz' else (B, 1, 2, N, N)
+    xis = [rs.randn(*shape) if kind == 'gz' else rs.randn(*shape).astype('float32') for _ in range(nsteps)]
+    members = sorted({0, B // 2, B - 1})
+    refs = {}
+    for b in members:
+        it = iter([x[b] for x in xis])
+
+        class _Rng:
+            def __init__(self, it):
+                self.it = it
+
+            def randn(self, *shp):
+                return next(self.it).astype('float64').reshape(shp)
+        m = qg_ref.QGModelRef(nx=N, **params)
+        m.sampling_type = sampling
+        m.noise_sampler = samplers_ref.make_sampler(sampling, nd)
+        m.q_parameterization = gen_ref.ParameterizationRef(ora, rng=_Rng(it))
+        m.set_q(q0[b])
+        refs[b] = m
+    draws = 0
+    for s in range(nsteps):
+        xi = torch.as_tensor(np.ascontiguousarray(xis[draws].reshape(B, 2, N, N))).cuda()
+        if sampling == 'AR1' or s % nd == 0:
+            draws += 1
+        e.step(1, generator=gen, sampling=sampling, nsteps_decor=nd, z_external=xi)
+        for m in refs.values():
+            m._step_forward()
+    qh = e.get(L.F_QH).cpu().numpy()
+    S = e.get(L.F_S).cpu().numpy()
+    for b, m in refs.items():
+        sc = np.abs(m.PV_forcing).max(axis=(1, 2), keepdims=True)
+        assert (np.abs(S[b] - m.PV_forcing) / sc).max() < 5e-5, (N, B, kind, b)
+        assert _rel(qh[b], m.qh) < 2e-6, (N, B, kind, b)
+    assert gen.range_ok() is None
+
+
+def dt_for(N):
+    return 14400. if N <= 64 else 7200.
