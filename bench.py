@@ -141,7 +141,7 @@ def mfma_roofline(gen, precision, N, B, kname, traffic):
     peak = F32_MFMA_PEAK_TFLOPS if precision == 'f32' else F16_MFMA_PEAK_TFLOPS
     r = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
          'frac': achieved / peak, 'traffic': traffic, 'flop_per_launch': flop, 'avg_launch_ms': avg_s * 1e3,
-         'launches_timed': n,
+         'launches_timed': n, 'launches_timed_note': 'HIP events bracket every 10th launch of the timed region',
          'peak_note': ('dense f32 MFMA peak; ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)' if precision == 'f32'
                        else 'dense f16 MFMA peak; `achieved` counts ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)')}
     if precision == 'f16x3':
@@ -214,6 +214,7 @@ def leg_config3(qa, device, K, W):
     eng.set_q(eddy_like_q(np.arange(B), N))
     loop = OnlineLoop(eng, dt, dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024))
     loop.run(W)
+    gen.set_option('prof_every', 10)
     gen.profile(1)
     el = timed(lambda: loop.run(K))
     roof = mfma_roofline(gen, 'f16x3', N, B, 'k_convh2<128,64,5x5> at 96x96 (generator layer 2)',
@@ -333,6 +334,7 @@ def main():
             dist.barrier()
 
     loop.run(W)
+    gen.set_option('prof_every', 10)    # HIP events around every 10th launch: each pair idles the GPU for ~12 us
     gen.profile(1)                      # dominant kernel: conv layer 2 (128->64, 5x5), 75% of the FLOPs
     elapsed = timed(lambda: loop.run(K), barrier)
     if dist is not None:

@@ -833,6 +833,8 @@ struct qgx_generator {
     float calib_max[10] = {0};     // [0..6] stored (post-BatchNorm) activations, [8] layer 1 before its BatchNorm
     int auto_precision = 3, auto_fold = 1, auto_ascale_log2 = 0;   // what calibrate() decided
     int prof_layer = -1;
+    int prof_every = 1;                 // bracket every n-th launch of the profiled layer ("prof_every" option)
+    long prof_seen = 0;
     std::vector<hipEvent_t> prof_ev;    // pairs (start, stop)
     size_t prof_used = 0;
 };
@@ -1053,6 +1055,8 @@ static int choose_rows(int N) {
 static int prof_begin(qgx_generator *g, int layer, hipStream_t st, hipEvent_t &stop) {
     stop = nullptr;
     if (g->prof_layer != layer) return QGX_OK;
+    // an event pair costs ~6 us of idle GPU on each side of the kernel: bracket every prof_every-th launch only
+    if (g->prof_every > 1 && (g->prof_seen++ % g->prof_every) != 0) return QGX_OK;
     if (g->prof_used + 2 > g->prof_ev.size()) {
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
@@ -2079,6 +2083,7 @@ extern "C" int qgx_generator_profile(qgx_generator *g, int layer) {
     QGX_REQUIRE(g && layer >= -1 && layer < 8, "qgx_generator_profile: bad argument");
     g->prof_layer = layer;
     g->prof_used = 0;
+    g->prof_seen = 0;
     return QGX_OK;
 }
 
@@ -2127,6 +2132,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
     else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= -24 && value <= 24, "ascale_log2 must be in -24..24"); g->opt_ascale = ldexpf(1.f, value); }
+    else if (!strcmp(name, "prof_every")) { QGX_REQUIRE(value >= 1, "prof_every must be >= 1"); g->prof_every = value; }
     else if (!strcmp(name, "auto")) { g->opt_precision = g->auto_precision; g->opt_fold = g->auto_fold; g->opt_ascale = ldexpf(1.f, g->auto_ascale_log2); }
     else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);

@@ -371,4 +371,4 @@ def test_bench_two_rank_rehearsal_over_gloo():
     assert out['n_gpus'] == 2 and out['config']['total_members'] == 8 and out['scaling'] == 'weak'
     assert out['healthy'] and out['value'] > 0 and out['config']['cadence']['snapshots_in_timed_region'] == 1
     assert abs(out['value'] - 8 * 260 / (out['ms_per_step'] * 260e-3)) < 1e-6 * out['value']
-    assert out['roofline']['launches_timed'] == 260 and 0 < out['roofline']['frac'] < 1
+    assert out['roofline']['launches_timed'] == 26 and 0 < out['roofline']['frac'] < 1      # every 10th launch is bracketed
