@@ -372,3 +372,37 @@ def test_bench_two_rank_rehearsal_over_gloo():
     assert out['healthy'] and out['value'] > 0 and out['config']['cadence']['snapshots_in_timed_region'] == 1
     assert abs(out['value'] - 8 * 260 / (out['ms_per_step'] * 260e-3)) < 1e-6 * out['value']
     assert out['roofline']['launches_timed'] == 26 and 0 < out['roofline']['frac'] < 1      # every 10th launch is bracketed
+
+
+def test_offline_predict_returns_the_reference_dataset_layout(tmp_path):
+    """predict(ds, M) (cgan_regression.py:173-189, mean_var_model.py:117-135): one sample, mean and variance of the
+    forcing for every snapshot of a dataset with q (run, time, lev, y, x)."""
+    from pyqg_generative_amd.models import CGANRegression, MeanVarModel
+    from pyqg_generative_amd.tools.simulate import dataset_backend
+    import torch.nn.functional as F
+    xr = dataset_backend()
+    g = golden('generator.npz')
+    N = 64
+    q = np.stack([g['gan_64_q'], 0.5 * g['gan_64_q'], -g['gan_64_q']]).astype('float64').reshape(1, 3, 2, N, N)
+    ds = xr.Dataset({'q': (['run', 'time', 'lev', 'y', 'x'], q)})
+    gan = CGANRegression(folder=_model_folder(tmp_path, 'gan'))
+    out = gan.predict(ds, M=6, seed=2)
+    for name in ('q_forcing_advection', 'q_forcing_advection_mean', 'q_forcing_advection_var'):
+        assert out[name].dims == ('run', 'time', 'lev', 'y', 'x') and out[name].shape == q.shape
+    sample, mean, var = gan.generate_mean_var(q.reshape(3, 2, N, N), M=6, seed=2)
+    np.testing.assert_array_equal(np.asarray(out['q_forcing_advection_mean'].values).reshape(3, 2, N, N), mean)
+    assert (np.asarray(out['q_forcing_advection_var'].values) >= 0).all()
+    # Guillaumin-Zanna: mean net, softplus variance net against the oracle; the sample is mean + sqrt(var) * N(0,1)
+    gz = MeanVarModel(folder=_model_folder(tmp_path, 'gz'))
+    og = load_generator('gz')
+    o2 = gz.predict(ds, seed=3)
+    X = og.x_scale.normalize(q.reshape(3, 2, N, N).astype('float32'))
+    mref = og.y_scale.denormalize(gen_ref.cnn_forward(og.nets[0], X))
+    vref = F.softplus(torch.as_tensor(gen_ref.cnn_forward(og.nets[1], X))).numpy() * og.y_scale.std ** 2
+    m2 = np.asarray(o2['q_forcing_advection_mean'].values).reshape(3, 2, N, N)
+    v2 = np.asarray(o2['q_forcing_advection_var'].values).reshape(3, 2, N, N)
+    assert np.abs(m2 - mref).max() < 2e-5 * np.abs(mref).max()
+    assert np.abs(v2 - vref).max() < 5e-5 * np.abs(vref).max()
+    s2 = np.asarray(o2['q_forcing_advection'].values).reshape(3, 2, N, N)
+    zs = (s2 - m2) / np.sqrt(v2)
+    assert abs(zs.mean()) < 0.02 and abs(zs.std() - 1) < 0.02
