@@ -807,6 +807,8 @@ struct qgx_generator {
     unsigned long long *stamps = nullptr;   // diagnostic builds only
     int stamp_layer = -1;
     int opt_h2_tw32 = 0;           // 5x5 layer at 64 x 64: 16-row x 32-column tiles instead of 8 full rows
+    int opt_h2_x96 = 1;            // 3x3 layers at 96 x 96 as 8-wave workgroups on 16-row x 32-column tiles (-1.4 % of the step at 32 members, -3.6 % at 64)
+    int opt_h2_w8_min96 = 1024;    // 5x5 layer at 96 x 96: minimum tile count for the 8-wave x-tiled kernel
     int opt_h2_w8 = 3;             // k_convh2 as one 8-wave workgroup per CU: bit 0 the 5x5 layer, bit 1 the 3x3 layers (64 x 64)
     int opt_prio_alt = 1;          // k_convh2 with two workgroups per CU: alternate their wave priority per tile
     int opt_h4 = 0;                // 5x5 layer: k_convh4 (full-line patch chunks, 8 waves, R = 8)
@@ -1465,10 +1467,10 @@ static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, con
 }
 
 // the 3x3 layers in the same 8-wave shape (64 x 64)
-template <int CIN, bool OUTF32>
+template <int CIN, bool OUTF32, int NN = 64, int TW = NN>
 static int launch_convh2_w8_3x3(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, hipStream_t st) {
-    constexpr int COUT = 32, KS = 3, NN = 64, MT = 2, TPS = 9, NW = 8;
-    constexpr int R = NW * MT * 32 / NN, PR = R + KS - 1, PW = NN + 2;
+    constexpr int COUT = 32, KS = 3, MT = 2, TPS = 9, NW = 8;
+    constexpr int R = NW * MT * 32 / TW, PR = R + KS - 1, PW = TW + 2;
     constexpr size_t lds = (size_t)PR * PW * 80 + (size_t)2 * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
@@ -1478,10 +1480,10 @@ static int launch_convh2_w8_3x3(qgx_generator *g, int layer, const LayerHost &L,
     a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = NN; a.R = R;
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
-    const int total_tiles = B * (NN / R);
+    const int total_tiles = B * (NN / R) * (NN / TW);
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
-    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, true, false, true, false, NW>;
+    auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, true, false, true, false, NW, TW>;
     QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
@@ -1495,6 +1497,9 @@ static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const 
     done = true;
     if constexpr (KS == 3 && COUT == 32) {
         if ((g->opt_h2_w8 & 2) && g->opt_pair && N == 64 && B * 8 >= 256) return launch_convh2_w8_3x3<CIN, OUTF32>(g, layer, L, in, out, B, st);
+        // 96 = 3 x 32: tiles of 16 rows x 32 columns give the 3x3 layers the two-M-tiles-per-wave 8-wave shape too
+        if ((g->opt_h2_w8 & 2) && g->opt_pair && g->opt_h2_x96 && N == 96 && B * 18 >= 256)
+            return launch_convh2_w8_3x3<CIN, OUTF32, 96, 32>(g, layer, L, in, out, B, st);
     }
     if constexpr (KS == 5 && CIN == 128) {
         // one 8-wave workgroup per CU once its double-height tiles fill the CUs: -5.5 % at 64 x 64, -3.5 % at
@@ -1504,7 +1509,7 @@ static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const 
                 return g->opt_h2_tw32 ? launch_convh2_w8<64, 2, 32>(g, layer, L, in, out, B, st) : launch_convh2_w8<64, 2>(g, layer, L, in, out, B, st);
             if (N == 32 && B * 2 >= 256) return launch_convh2_w8<32, 2>(g, layer, L, in, out, B, st);
             // 96 = 3 x 32: tiles of 16 rows x 32 columns keep the two-M-tiles-per-wave shape
-            if (N == 96 && B * 18 >= 1024) return launch_convh2_w8<96, 2, 32>(g, layer, L, in, out, B, st);
+            if (N == 96 && B * 18 >= g->opt_h2_w8_min96) return launch_convh2_w8<96, 2, 32>(g, layer, L, in, out, B, st);
         }
     }
     switch (N) {
@@ -2128,6 +2133,8 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "prio_alt")) g->opt_prio_alt = value;
     else if (!strcmp(name, "h2_w8")) g->opt_h2_w8 = value & 3;
     else if (!strcmp(name, "h2_tw32")) g->opt_h2_tw32 = value ? 1 : 0;
+    else if (!strcmp(name, "h2_x96")) g->opt_h2_x96 = value ? 1 : 0;
+    else if (!strcmp(name, "h2_w8_min96")) g->opt_h2_w8_min96 = value;
     else if (!strcmp(name, "half_min_tiles")) { QGX_REQUIRE(value >= 1, "half_min_tiles must be >= 1"); g->opt_half_min_tiles = value; }
     else if (!strcmp(name, "first_h")) g->opt_first_h = value ? 1 : 0;
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }

@@ -99,6 +99,7 @@ VARIANTS = [                                     # selectable variants of the pr
     dict(fuse=7),                                # every 3x3 pair fused (k_convh_pair)
     dict(fuse=2), dict(fuse=0),
     dict(h2_w8=0), dict(h2_w8=1),                # 4-wave x 2 workgroups per CU instead of one 8-wave workgroup
+    dict(h2_x96=0), dict(h2_w8_min96=1),         # 96 x 96: 4-wave full-row 3x3 kernels / x-tiled 8-wave 5x5 kernel at any size
     dict(first_h=0),                             # exact-f32 first layer writing the 16-bit layout
     dict(fold=0),                                # layer 1's BatchNorm applied in its epilogue instead of folded into layer 2
     dict(member_chunk=16),                       # member sub-batches
@@ -111,7 +112,7 @@ AB_VARIANTS = [                                  # kernels of the A/B library on
     dict(h3=1),                                  # 5x5 layer on 16x16x32 MFMAs (k_convh3)
     dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
 ]
-DEFAULTS = dict(fuse=3, pair=1, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h2_w8=3, ascale_log2=0)
+DEFAULTS = dict(fuse=3, pair=1, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h2_w8=3, ascale_log2=0, h2_x96=1, h2_w8_min96=1024)
 AB_DEFAULTS = dict(DEFAULTS, h2=3, half_nw=8, res=1, h3=0, h4=0)
 
 
@@ -128,7 +129,7 @@ def _variant_errors(gen, x, variants, defaults):
     return ref, errs
 
 
-@pytest.mark.parametrize('N,B', [(64, 32), (96, 8), (48, 16)])
+@pytest.mark.parametrize('N,B', [(64, 32), (96, 8), (96, 32), (48, 16)])
 def test_optional_kernel_variants_agree(N, B):
     """every selectable f16x3 kernel variant of the product library against the exact-f32 path: float32
     tolerance (2e-5 of the maximum); options that do not apply to a grid size fall back to the default kernels"""
