@@ -162,6 +162,9 @@ def test_ab_library_variants_agree():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out['version'].endswith('+ab')
+    from pyqg_generative_amd import _lib
+    # both libraries were built from the same sources (fingerprint in qgx_version, tests/test_abi_cpu.py)
+    assert out['version'].split(' +ab')[0] == _lib.lib.qgx_version().decode().split(' +ab')[0]
     for key, errs in out['f16x3'].items():
         assert max(errs) < 2e-5, (key, errs)
     for key, errs in out['f16'].items():
