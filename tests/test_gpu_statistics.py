@@ -81,3 +81,57 @@ def test_parameterized_48_run_reaches_published_equilibrium(kind):
     assert 4.0e-4 < kes[-1] < 8.0e-4, kes
     assert kes[-1] > 20 * kes[0]                    # spin-up from the 1e-7 initial noise happened
     m.close()
+
+
+@pytest.mark.parametrize('case', ['eddy64_gan', 'jet96_vae'])
+def test_parameterized_ensemble_statistics_match_cpu_oracle(case):
+    """North-star criterion for the PARAMETERIZED configurations (BASELINE configs[1]/[2]: 64x64 eddy + CGAN;
+    configs[3]: 96x96 jet + CVAE): the time-mean isotropic KE spectrum and the time-mean KE of a 16-member GPU
+    ensemble against 8 members of the CPU oracle run with the same protocol (same initial-condition distribution,
+    sampling='constant' nsteps=1, same averaging window).  The oracle members are cached
+    (tests/golden/oracle_stats_<case>.npz written by tests/golden/make_oracle_stats.py: 5-35 CPU-minutes per member).
+    Stated tolerance per wavenumber bin of the energy-containing range: 4 standard errors of the difference of the
+    two ensemble means (member-to-member spread measured on both sides) + 5 % of the oracle value."""
+    import os
+    from conftest import GOLDEN
+    from pyqg_generative_amd import weights
+    from pyqg_generative_amd.tools.simulate import set_initial_condition
+    from pyqg_generative_amd.tools.stochastic_pyqg import stochastic_QGModel
+    from pyqg_generative_amd.tools.spectral_tools import calc_ispec
+    from pyqg_generative_amd.models import CGANRegression, CVAERegression
+    path = os.path.join(GOLDEN, f'oracle_stats_{case}.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{path} not generated (tests/golden/make_oracle_stats.py {case})')
+    ref = np.load(path)
+    kind, N, params = {'eddy64_gan': ('gan', 64, dict(dt=14400.)),
+                       'jet96_vae': ('vae', 96, dict(dt=7200., rek=7e-8, delta=0.1, beta=1e-11))}[case]
+    nsteps, tave = int(ref['nsteps']), int(ref['tave'])
+    nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind)
+    model = {'gan': CGANRegression, 'vae': CVAERegression}[kind].from_arrays(nets, xs, ys)
+    B, dt = 16, params['dt']
+    m = stochastic_QGModel(dict(nx=N, tmax=dt * nsteps, tavestart=dt * tave, taveint=86400., twrite=5000, log_level=0,
+                                parameterization=model, **params), 'constant', 1, n_members=B, seed=77)
+    set_initial_condition(m, seeds=range(2000, 2000 + B))
+    m.run()
+    assert np.all(m.cfl < 1)
+    spec = m.get_diagnostic('KEspec')                                     # (B, 2, N, N/2+1) time means
+    delta = params.get('delta', 0.25)
+
+    def iso(members):      # the reference's metric, per member: calc_ispec(m, 0.5 * ave_lev(KEspec, delta))
+        return calc_ispec(m, 0.5 * (delta * members[:, 0] + members[:, 1]) / (1 + delta))
+    kr, g = iso(spec)
+    _, c = iso(ref['KEspec_members'].astype('float64'))
+    gm, cm = g.mean(0), c.mean(0)
+    se = np.sqrt(g.var(0, ddof=1) / g.shape[0] + c.var(0, ddof=1) / c.shape[0])
+    band = (kr > 2 * m.dk) & (kr < (N // 3) * m.dk) & (cm > 1e-3 * cm.max())
+    diff = np.abs(gm - cm)[band]
+    tol = (4 * se + 0.05 * cm)[band]
+    print(f'\n{case}: isotropic KE spectrum, |GPU - CPU| / CPU per bin', np.round(diff / cm[band], 3),
+          ' tolerance / CPU', np.round(tol / cm[band], 3))
+    assert np.all(diff <= tol), (diff / cm[band], tol / cm[band])
+    # time-mean KE over the averaging window (Parseval sum of the spectra), ensemble means
+    ke_g, ke_c = g.sum(1) * (kr[1] - kr[0]), c.sum(1) * (kr[1] - kr[0])
+    se_ke = np.sqrt(ke_g.var(ddof=1) / len(ke_g) + ke_c.var(ddof=1) / len(ke_c))
+    print(f'{case}: time-mean KE (spectral sum) GPU {ke_g.mean():.4e} CPU {ke_c.mean():.4e}, standard error {se_ke:.1e}')
+    assert abs(ke_g.mean() - ke_c.mean()) <= 4 * se_ke + 0.05 * ke_c.mean()
+    m.close()
