@@ -38,7 +38,7 @@ MAC_PER_PIXEL = [12800, 204800, 18432, 9216, 9216, 9216, 9216, 576]   # SURVEY Â
 F32_MFMA_PEAK_TFLOPS = 157.3                                           # MI355X_MICROARCH.md, dense f32 matrix
 F16_MFMA_PEAK_TFLOPS = 2500.0                                          # dense f16/bf16, same guide
 HBM_PEAK_GBS = 8000.0                                                  # HBM3E, same guide
-PRECISIONS = {'f32': 0, 'f16x3': 3, 'f16': 1}
+PRECISIONS = {'f32': 0, 'f16x3': 3}
 JET = dict(rek=7e-8, delta=0.1, beta=1e-11)                            # tools/parameters.py:26-27,37
 
 
@@ -137,7 +137,6 @@ def mfma_roofline(gen, precision, N, B, kname, traffic):
     flop = 2.0 * MAC_PER_PIXEL[1] * N * N * B
     avg_s = (ms / max(n, 1)) * 1e-3
     achieved = flop / avg_s / 1e12 if avg_s > 0 else 0.0
-    mfma_per_mac = {'f32': 1, 'f16x3': 3, 'f16': 1}[precision]
     peak = F32_MFMA_PEAK_TFLOPS if precision == 'f32' else F16_MFMA_PEAK_TFLOPS
     r = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
          'frac': achieved / peak, 'traffic': traffic, 'flop_per_launch': flop, 'avg_launch_ms': avg_s * 1e3,
@@ -286,7 +285,7 @@ def main():
     ap.add_argument('--kind', default='gan', choices=['gan', 'vae', 'gz'])
     ap.add_argument('--precision', default='f16x3', choices=list(PRECISIONS),
                     help='generator conv arithmetic: f16x3 = hi/lo split f16 MFMA, f32-class accuracy (default); '
-                         'f32 = exact f32 MFMA; f16 = plain f16 operands (TF32-class)')
+                         'f32 = exact f32 MFMA')
     ap.add_argument('--no-aux', action='store_true', help='skip exact_f32 / b1 / config3 / config4 legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--leg', default='all', choices=['all', 'config3', 'config4'],
@@ -349,8 +348,7 @@ def main():
         total_members = B * world
         value = total_members * K / elapsed
         cfg = {'nx': N, 'members_per_gpu': B, 'kind': args.kind}
-        traffic = {'f32': pmc_traffic('pmc_traffic.json', cfg), 'f16x3': pmc_traffic('pmc_traffic_f16x3.json', cfg),
-                   'f16': None}[args.precision]
+        traffic = {'f32': pmc_traffic('pmc_traffic.json', cfg), 'f16x3': pmc_traffic('pmc_traffic_f16x3.json', cfg)}[args.precision]
         kname = ('k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh2<128,64,5x5>') + ' (generator layer 2)'
         roof = mfma_roofline(gen, args.precision, N, B, kname, traffic)
         gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
@@ -358,8 +356,7 @@ def main():
         dtype = {'f32': 'f64 spectral core + f32 generator (exact-f32 MFMA)',
                  'f16x3': 'f64 spectral core + f32-class generator: f16 hi/lo split operands, 3 f16 MFMAs per '
                           'product, f32 accumulate (error vs a float64 ground truth <= the exact-f32 path, '
-                          'tests/test_gpu_precision.py)',
-                 'f16': 'f64 spectral core + f16-operand generator (f32 accumulate, TF32-class)'}[args.precision]
+                          'tests/test_gpu_precision.py)'}[args.precision]
         out = {
             'metric': 'ensemble-timesteps/sec, 64^2 2-layer eddy + GAN param',
             'value': value, 'unit': 'ensemble-timesteps/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
