@@ -71,6 +71,14 @@ def main():
         save[k + '_mean'] = a.mean(0)
         save[k + '_std'] = a.std(0, ddof=1)          # member-to-member spread of the time means
     save['KEspec_members'] = np.stack([r['KEspec'] for r in res]).astype('float32')   # per member: sampling error of derived spectra
+    # a run that blew up (the shipped, eddy-trained CVAE on the jet configuration does, in every member, between steps
+    # 24,000 and 33,500) keeps only what is meaningful: the KE series up to the blow-up and the step it happened at
+    ke = save['ke_series']
+    bad = ~np.isfinite(ke)
+    save['first_nonfinite_step'] = np.where(bad.any(1), (bad.argmax(1) + 1) * 500, -1)
+    if bad.any():
+        save = {k: v for k, v in save.items() if not (isinstance(v, np.ndarray) and v.dtype.kind == 'f' and
+                                                       not np.isfinite(v).all() and k != 'ke_series')}
     path = os.path.join(ROOT, 'tests', 'golden', f'oracle_stats_{case}.npz')
     np.savez_compressed(path, **save)
     print('wrote', path, 'final KE per member', save['ke_series'][:, -1])

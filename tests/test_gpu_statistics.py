@@ -83,10 +83,10 @@ def test_parameterized_48_run_reaches_published_equilibrium(kind):
     m.close()
 
 
-@pytest.mark.parametrize('case', ['eddy64_gan', 'jet96_vae'])
+@pytest.mark.parametrize('case', ['eddy64_gan'])
 def test_parameterized_ensemble_statistics_match_cpu_oracle(case):
-    """North-star criterion for the PARAMETERIZED configurations (BASELINE configs[1]/[2]: 64x64 eddy + CGAN;
-    configs[3]: 96x96 jet + CVAE): the time-mean isotropic KE spectrum and the time-mean KE of a 16-member GPU
+    """North-star criterion for the PARAMETERIZED configuration (BASELINE configs[1]/[2]: 64x64 eddy + CGAN):
+    the time-mean isotropic KE spectrum and the time-mean KE of a 16-member GPU
     ensemble against 8 members of the CPU oracle run with the same protocol (same initial-condition distribution,
     sampling='constant' nsteps=1, same averaging window).  The oracle members are cached
     (tests/golden/oracle_stats_<case>.npz written by tests/golden/make_oracle_stats.py: 5-35 CPU-minutes per member).
@@ -134,4 +134,45 @@ def test_parameterized_ensemble_statistics_match_cpu_oracle(case):
     se_ke = np.sqrt(ke_g.var(ddof=1) / len(ke_g) + ke_c.var(ddof=1) / len(ke_c))
     print(f'{case}: time-mean KE (spectral sum) GPU {ke_g.mean():.4e} CPU {ke_c.mean():.4e}, standard error {se_ke:.1e}')
     assert abs(ke_g.mean() - ke_c.mean()) <= 4 * se_ke + 0.05 * ke_c.mean()
+    m.close()
+
+
+def test_jet96_cvae_transient_and_blow_up_match_cpu_oracle():
+    """BASELINE configs[3] (96x96 jet + the shipped CVAE) as a long run: the shipped decoder was trained on the eddy
+    configuration, and on the jet configuration EVERY member of the CPU oracle — i.e. the reference's own algorithm —
+    grows through KE ~ 2e-4 at step 20,000 and blows up between steps 24,500 and 34,000
+    (tests/golden/oracle_stats_jet96_vae.npz).  The configuration is therefore a throughput / per-step-parity case
+    (tests/test_gpu_parity.py, bench.py `config3`), and what a long run can be held to is the SAME transient: the
+    ensemble-mean log-KE of 16 GPU members at steps 10,000 / 15,000 / 20,000 within 4 standard errors + 0.15 of the
+    oracle's, and the same fate afterwards (caught by the CFL check, as pyqg would)."""
+    import os
+    from conftest import GOLDEN
+    from pyqg_generative_amd import weights
+    from pyqg_generative_amd.tools.simulate import set_initial_condition
+    from pyqg_generative_amd.tools.stochastic_pyqg import stochastic_QGModel
+    from pyqg_generative_amd.models import CVAERegression
+    ref = np.load(os.path.join(GOLDEN, 'oracle_stats_jet96_vae.npz'))
+    ke_c = ref['ke_series']                                     # (8, 86): KE every 500 steps, NaN after the blow-up
+    assert (ref['first_nonfinite_step'] > 24000).all() and (ref['first_nonfinite_step'] <= 34000).all()
+    nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, 'weights_vae.npz'), 'vae')
+    model = CVAERegression.from_arrays(nets, xs, ys)
+    B, dt = 16, 7200.
+    m = stochastic_QGModel(dict(nx=96, dt=dt, tmax=dt * 40000, twrite=500, log_level=0, rek=7e-8, delta=0.1, beta=1e-11,
+                                parameterization=model), 'constant', 1, n_members=B, seed=5)
+    set_initial_condition(m, seeds=range(3000, 3000 + B))
+    ke_g = {}
+    blew_up_at = None
+    try:
+        for _ in m.run_with_snapshots(tsnapint=dt * 5000):
+            ke_g[m.tc] = np.asarray(m.ke)
+    except (AssertionError, FloatingPointError):
+        blew_up_at = m.tc
+    for step in (10000, 15000, 20000):
+        lg, lc = np.log(ke_g[step]), np.log(ke_c[:, step // 500 - 1])
+        se = np.sqrt(lg.var(ddof=1) / len(lg) + lc.var(ddof=1) / len(lc))
+        print(f'\njet 96 + CVAE, step {step}: mean log KE GPU {lg.mean():.3f} CPU {lc.mean():.3f} (standard error {se:.3f})')
+        assert abs(lg.mean() - lc.mean()) <= 4 * se + 0.15, step
+    # the first GPU member to violate CFL / go non-finite does so in the window the oracle members do
+    print('GPU ensemble stopped at step', blew_up_at, '; oracle members at', ref['first_nonfinite_step'])
+    assert blew_up_at is not None and 22000 <= blew_up_at <= 34000
     m.close()
