@@ -222,7 +222,9 @@ def leg_config3(qa, device, K, W):
     out = {'workload': f'BASELINE configs[3] shard: jet {N}x{N} + CVAE, {B} members on 1 GPU (256 members / 8 GPUs), '
                        f"sampling='constant' nsteps=1, dt={dt:.0f}s",
            'value': B * K / el, 'unit': 'ensemble-timesteps/sec', 'steps': K, 'ms_per_step': 1e3 * el / K,
-           'roofline': roof, 'healthy': bool(np.isfinite(ke).all() and (cfl < 1).all())}
+           'roofline': roof, 'healthy': bool(np.isfinite(ke).all() and (cfl < 1).all()),
+           'note': 'throughput configuration: with the shipped (eddy-trained) CVAE a LONG jet run blows up after ~24,000 '
+                   'steps in the CPU oracle too (DESIGN.md section 4, tests/test_gpu_statistics.py)'}
     eng.close()
     gen.close()
     return out
