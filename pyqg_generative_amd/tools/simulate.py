@@ -117,7 +117,7 @@ def run_simulation(pyqg_params, parameterization=None, q_init=None, sampling_fre
 
 
 def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n_members=1, seeds=None,
-                             device=0, operators=('Operator2', 'Operator5')):
+                             device=0, operators=('Operator2', 'Operator5'), dealias='3/2-rule'):
     """Forcing-dataset generation (reference: simulate.py:62-106): run the high-resolution model given
     by pyqg_params and, every ``sampling_freq`` seconds, coarse-grain the PV to each resolution in Nc
     with each operator and diagnose the subgrid forcing with 3/2-rule dealiasing.  Returns
@@ -140,7 +140,7 @@ def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n
         for opname in operators:
             dev_op = getattr(Dev, opname)
             for nc in Nc:
-                forcing, qf, uf, vf, psi = Dev.PV_subgrid_forcing(qd, nc, dev_op, coarse_params, '3/2-rule',
+                forcing, qf, uf, vf, psi = Dev.PV_subgrid_forcing(qd, nc, dev_op, coarse_params, dealias,
                                                                   return_psi=True)
                 data = {'q_forcing_advection': (dims, pack(forcing)), 'q': (dims, pack(qf)),
                         'u': (dims, pack(uf)), 'v': (dims, pack(vf)), 'psi': (dims, pack(psi))}
@@ -149,7 +149,8 @@ def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n
                           'lev': (('lev',), np.arange(1, 3)), 'x': (('x',), xc), 'y': (('y',), xc)}
                 if B > 1:
                     coords['run'] = (('run',), np.arange(m.member_offset, m.member_offset + B))
-                out.setdefault(f'{opname}-{nc}-dealias', []).append(xr.Dataset(data, coords=coords))
+                out.setdefault(f'{opname}-{nc}' + ('-dealias' if dealias != 'none' else ''), []).append(
+                    xr.Dataset(data, coords=coords))
     attrs = dict(m.to_dataset(variables=()).attrs)          # simulate.py:105: the hires model's pyqg:* attributes
     attrs['pyqg_params'] = str(pyqg_params)
     for key in out:
