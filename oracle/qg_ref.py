@@ -1,9 +1,13 @@
 """CPU restatement (numpy, float64) of the 2-layer pseudo-spectral QG core.
 
-TEST INFRASTRUCTURE — see oracle/__init__.py.  PARITY UNPINNED: the arithmetic
-restated here lives in the third-party package ``pyqg`` (version 0.7.2 in the
-reference's published logs, Google-Colab/online-simulations.ipynb:40,99), which
-is neither vendored under /root/reference nor installable offline.  The
+TEST INFRASTRUCTURE — see oracle/__init__.py.  PARITY UNPINNED at step level: the
+arithmetic restated here lives in the third-party package ``pyqg`` (version 0.7.2 in
+the reference's published logs, Google-Colab/online-simulations.ipynb:40,99), which
+is neither vendored under /root/reference nor installable offline, and the reference
+holds no per-step fixture of it.  What the reference does hold is two published
+checksums of a dataset produced by real pyqg (Google-Colab/dataset.ipynb cell 16);
+tests/test_oracle_qg.py holds a cached long run of this restatement to them
+(tests/golden/make_oracle_forcing_stats.py), statistically.  The
 restatement follows pyqg 0.7.2's published algorithm
 
     pyqg/model.py      _initialize_grid, _initialize_filter, _initialize_time,
