@@ -187,3 +187,25 @@ def test_published_48x48_log_is_reproduced():
     for a, b in ((4000, 5000), (5000, 6000), (6000, 7000)):
         assert 2.4 < ke[b] / ke[a] < 3.4, (a, b, ke[b] / ke[a])
     assert 1e-8 < ke[1000] < 5e-6          # published: 1.4e-7 .. 5.7e-7 at step 1000 (unseeded initial conditions)
+
+
+def test_oracle_long_run_matches_the_references_published_dataset_checksums():
+    """The DIRECT pin of this restatement against real pyqg output: the reference publishes the std of the coarse-grained
+    PV and of the subgrid forcing of its dataset `eddy/64/sharp` (Google-Colab/dataset.ipynb cell 16; 300 runs of
+    256 x 256, 10 years, Operator1, no dealiasing).  Eight oracle members run with that protocol are cached in
+    tests/golden/oracle_forcing_dataset_stats.npz (per-member sums; ~10 CPU-minutes per member,
+    tests/golden/make_oracle_forcing_stats.py).  Stated tolerance: 4 standard errors of the 8-member estimate + 0.3 %."""
+    import os
+    import pytest
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_forcing_dataset_stats.npz')
+    if not os.path.exists(path):
+        pytest.skip('tests/golden/oracle_forcing_dataset_stats.npz not generated')
+    s = np.load(path)['sums']                       # columns: n_q, sum_q, sum_q2, n_f, sum_f, sum_f2, snapshots
+    assert s.shape[0] >= 4 and (s[:, 6] == 86).all()
+    for (n, s1, s2), published in (((0, 1, 2), 5.701264812550008e-06), ((3, 4, 5), 4.999136229013802e-12)):
+        tot = s.sum(0)
+        total = np.sqrt(tot[s2] / tot[n] - (tot[s1] / tot[n]) ** 2)
+        per_run = np.sqrt(s[:, s2] / s[:, n] - (s[:, s1] / s[:, n]) ** 2)
+        se = per_run.std(ddof=1) / np.sqrt(len(per_run))
+        print(f'oracle {total:.6e} published {published:.6e} ({100 * (total / published - 1):+.3f} %), standard error {100 * se / published:.2f} %')
+        assert abs(total - published) <= 4 * se + 0.003 * published
