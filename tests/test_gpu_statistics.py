@@ -198,6 +198,11 @@ def test_forcing_dataset_matches_the_references_published_checksums():
     assert ds['q'].dims == ('run', 'time', 'lev', 'y', 'x') and ds['q'].shape == (B, 86, 2, 64, 64)   # cell 14: time: 86
     assert ds['q'].dtype == np.float32
     np.testing.assert_allclose(float(np.asarray(ds['time'].values)[0]), 1000 * 3600 / 86400., rtol=1e-6)   # 41 days 16 h
+    # the hires model's attributes travel with the dataset (simulate.py:105; values printed in dataset.ipynb cell 14)
+    for key, val in (('pyqg:M', 65536), ('pyqg:tc', 86400), ('pyqg:del2', 0.8), ('pyqg:delta', 0.25), ('pyqg:beta', 1.5e-11),
+                     ('pyqg:L', 1000000.0), ('pyqg:W', 1000000.0), ('pyqg:tmax', 311040000), ('pyqg:twrite', 1000)):
+        assert ds.attrs[key] == val, (key, ds.attrs[key])
+    assert 'pyqg_params' in ds.attrs
     for name, published in (('q', PUBLISHED_STD_Q), ('q_forcing_advection', PUBLISHED_STD_FORCING)):
         a = np.asarray(ds[name].values).astype('float64')
         total = a.std()
