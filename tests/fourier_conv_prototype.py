@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Developer tool: feasibility of evaluating generator layer 2 (128 -> 64 channels, 5x5, CIRCULAR padding) in Fourier
+"""Experiment (imports the oracle, so it lives under tests/): feasibility of evaluating generator layer 2 (128 -> 64 channels, 5x5, CIRCULAR padding) in Fourier
 space — a per-wavenumber complex (64 x 128) matrix product, 12x fewer multiply-adds than the 25-tap stencil.
 
   * numerics (CPU, float32 FFTs + float32 products against a float64 direct convolution of the shipped GAN weights)
