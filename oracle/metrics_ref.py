@@ -1,4 +1,4 @@
-"""CPU restatement (numpy / scipy) of the reference's ONLINE METRICS: the distributional and spectral errors of a
+"""CPU restatement (numpy / scipy) of the reference's ONLINE and OFFLINE METRICS: the distributional and spectral errors of a
 low-resolution run against a coarse-grained high-resolution reference.
 
 TEST INFRASTRUCTURE — see oracle/__init__.py.  The reference publishes these numbers for its shipped models
@@ -9,6 +9,7 @@ HIP engine.  Reference followed (paths relative to /root/reference/pyqg_generati
                                       by the squared filter transfer function)
   tools/comparison_tools.py:116-195   diagnostic_differences_Perezhogin
   tools/spectral_tools.py:103-180     calc_ispec (oracle/spectral_ref.py, golden-pinned)
+  tools/computational_tools.py:38-84  subgrid_scores (offline metrics; Google-Colab/offline-analysis.ipynb cells 28-31)
 and, for the derived features 'add(pow(u,2),pow(v,2))' and 'pow(curl(u,v),2)', the FeatureExtractor of the un-vendored
 dependency pyqg_parameterization_benchmarks (utils.py): curl(u, v) = ddx(v) - ddy(u) with spectral derivatives on
 pyqg's grid of the fields' resolution.
@@ -95,4 +96,36 @@ def coarsegrain_reference_spectra(hires, resolution, operator='Operator1'):
     for name, a in hires.items():
         a = np.asarray(a)
         out[name] = np.concatenate((a[..., :n, :n + 1], a[..., -n:, :n + 1]), axis=-2) * tf2
+    return out
+
+
+# ---- offline metrics ---------------------------------------------------------------------------------------------
+def power_spectrum_iso(x):
+    """spectrum(type='power', averaging=False, truncate=False, time=slice(None)) of tools/spectral_tools.py:7-101 for
+    x (run, time, lev, N, N): run/time-mean power per lev, binned by calc_ispec.  -> (kr, (lev, nbins))"""
+    x = np.asarray(x, dtype='float64')
+    N = x.shape[-1]
+    af2 = (np.abs(np.fft.rfftn(x, axes=(-2, -1)) / (N * N)) ** 2).mean(axis=(0, 1))
+    g = QGModelRef(nx=N)
+    out = [calc_ispec(g, af2[z], averaging=False, truncate=False) for z in range(af2.shape[0])]
+    return out[0][0], np.stack([o[1] for o in out])
+
+
+def subgrid_scores(true, mean, gen):
+    """tools/computational_tools.py:38-84 on arrays (run, time, lev, N, N): relative L2 errors of the conditional mean,
+    of the power spectrum of one generated sample and of the spectrum of its residual, and the residual variance ratio.
+    -> dict(L2_mean, L2_total, L2_residual, var_ratio (lev,))"""
+    true, mean, gen = (np.asarray(a, dtype='float64') for a in (true, mean, gen))
+
+    def L2(x, xt, axes):
+        return float(((((x - xt) ** 2).mean(axes) / (xt ** 2).mean(axes)) ** 0.5).mean())     # per lev, then mean
+    field_axes = (0, 1, 3, 4)
+    out = {'L2_mean': L2(mean, true, field_axes)}
+    _, sp_true = power_spectrum_iso(true)
+    _, sp_gen = power_spectrum_iso(gen)
+    out['L2_total'] = L2(sp_gen, sp_true, (1,))
+    _, sp_true_res = power_spectrum_iso(true - mean)
+    _, sp_gen_res = power_spectrum_iso(gen - mean)
+    out['L2_residual'] = L2(sp_gen_res, sp_true_res, (1,))
+    out['var_ratio'] = ((gen - mean) ** 2).mean(field_axes) / ((true - mean) ** 2).mean(field_axes)
     return out
