@@ -33,6 +33,10 @@ int large_invert(qgx_model *m, hipStream_t st);
 int large_step(qgx_model *m, const StepArgs &a, hipStream_t st);
 int large_ensure_q(qgx_model *m, hipStream_t st);
 int large_zpad();
+int large_team_available(qgx_model *m, hipStream_t st);
+int large_team_check(qgx_model *m, hipStream_t st);
+int large_team_steps(qgx_model *m, int K, int ablevel0, const double coef[3][3], const double2 *qh_src, double2 *qh_dst,
+                     const double2 *p_src, const double2 *pp_src, double2 *p_dst, double2 *pp_dst, hipStream_t st);
 
 // One _step_forward: AB3 coefficient schedule of kernel.pyx::_forward_timestep, history rotation.
 static int model_step_once(qgx_model *m, bool has_S, const double *S, double weight, int demean, int diag,
@@ -60,6 +64,24 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
     m->i_pp = m->i_p; m->i_p = m->i_new; m->i_new = dead;
     m->cur_q ^= 1;
     m->tc += 1;
+    return QGX_OK;
+}
+
+// K unparameterized steps without diagnostics output in one launch of the XCD-resident kernel (spectral_large.hip):
+// the same AB3 schedule and history rotation as K calls of model_step_once.
+static int model_step_run(qgx_model *m, int K, hipStream_t st) {
+    const double dt = m->cfg.dt;
+    const double coef[3][3] = {{dt, 0.0, 0.0}, {1.5 * dt, -0.5 * dt, 0.0}, {23. / 12. * dt, -16. / 12. * dt, 5. / 12. * dt}};
+    int in = m->i_new, ip = m->i_p, ipp = m->i_pp;
+    for (int s = 0; s < K; ++s) { const int dead = ipp; ipp = ip; ip = in; in = dead; }
+    // before: i_new = T_{n-1}, i_p = T_{n-2}; after: the new i_new holds T_{n+K-1}, the new i_p holds T_{n+K-2}
+    int rc = large_team_steps(m, K, m->ablevel, coef, m->qh[m->cur_q], m->qh[m->cur_q ^ (K & 1)], m->dq[m->i_new],
+                              m->dq[m->i_p], m->dq[in], m->dq[ip], st);
+    if (rc) return rc;
+    m->i_new = in; m->i_p = ip; m->i_pp = ipp;
+    m->cur_q ^= (K & 1);
+    m->tc += K;
+    m->ablevel = m->ablevel + K > 2 ? 2 : m->ablevel + K;
     return QGX_OK;
 }
 
@@ -256,7 +278,7 @@ extern "C" int qgx_destroy(qgx_model *m) {
     if (!m) return QGX_OK;
     (void)hipSetDevice(m->cfg.device);
     void *ptrs[] = {m->t_filtr, m->t_wv2, m->t_a, m->t_kk, m->t_ll, m->t_tw, m->t_pos, m->q, m->u, m->v,
-                    m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->zbuf,
+                    m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->zbuf, m->team_ctl,
                     m->z, m->xi, m->dg_R[0], m->dg_R[1], m->dg_R[2], m->dg_R[3], m->dg_R[4], m->dg_S[0], m->dg_S[1],
                     m->dg_S[2], m->dg_S[3], m->dg_S[4], m->dg_acc[0], m->dg_acc[1], m->dg_acc[2], m->dg_acc[3],
                     m->dg_acc[4], m->dg_acc[5], m->dg_acc[6], m->dg_acc[7], m->dg_acc[8], m->dg_acc[9]};
@@ -278,6 +300,7 @@ extern "C" size_t qgx_field_bytes(const qgx_model *m, int field) {
 }
 
 extern "C" int qgx_get(qgx_model *m, int field, void *out_dev, void *stream) {
+    if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m && out_dev, "qgx_get: null argument");
     if (field == QGX_F_P)      // pyqg's derived field p = ifft(ph) (model.py::_calc_derived_fields), straight into the caller's buffer
         return m->small ? small_qh_to_q(m->d, m->ph, (double *)out_dev, (hipStream_t)stream)
@@ -334,6 +357,7 @@ extern "C" int qgx_set_qh(qgx_model *m, const double *qh_dev, void *stream) {
 }
 
 extern "C" int qgx_invert(qgx_model *m, void *stream) {
+    if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m, "qgx_invert: null model");
     hipStream_t st = (hipStream_t)stream;
     return m->small ? small_invert(m->d, m->qh[m->cur_q], m->ph, m->u, m->v, st) : large_invert(m, st);
@@ -350,6 +374,7 @@ extern "C" int qgx_reset_time(qgx_model *m) {
 }
 
 extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
+    if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m && out_dev, "qgx_status_ke_cfl: null argument");
     hipLaunchKernelGGL(k_status, dim3(m->B), dim3(256), 0, (hipStream_t)stream, m->d, m->ph, m->u, m->v, out_dev);
     QGX_HIP(hipGetLastError());
@@ -371,7 +396,28 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         QGX_REQUIRE(!(p->z_external_dev && nsteps != 1), "qgx_step: external noise needs nsteps_to_run == 1");
         m->z_double = generator_noise_is_double(p->gen);
     }
+    if (!m->small) { int trc = large_team_check(m, st); if (trc) return trc; }
+    const bool plain = !(p && (p->gen || p->forcing_dev));
     for (int s = 0; s < nsteps; ++s) {
+        if (plain && !m->small && large_team_available(m, st)) {
+            // a run of steps with no diagnostics increment due inside it and no (u, v, psi) refresh asked of it
+            const bool due = m->dg_every > 0 && m->tc >= 1 && m->tc >= m->dg_start && m->tc % m->dg_every == 0;
+            int K = 0;
+            const int last = refresh_diag ? nsteps - 1 : nsteps;          // the refreshing step takes the three-launch path
+            while (s + K < last) {
+                const int64_t t = m->tc + K;
+                if (K > 0 && m->dg_every > 0 && t >= 1 && t >= m->dg_start && t % m->dg_every == 0) break;
+                ++K;
+            }
+            const int kmin = getenv("QGX_LARGE_TEAM_MIN") ? atoi(getenv("QGX_LARGE_TEAM_MIN")) : 2;   // tuning aid
+            if (K >= kmin) {
+                if (due) { int drc = diag_increment(m, nullptr, 1.0, st); if (drc) return drc; }
+                int rc = model_step_run(m, K, st);
+                if (rc) return rc;
+                s += K - 1;
+                continue;
+            }
+        }
         bool has_S = false;
         const double *S = nullptr;
         double weight = 1.0;

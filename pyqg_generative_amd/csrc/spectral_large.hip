@@ -716,4 +716,447 @@ int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
     return QGX_OK;
 }
 
+
+// ================================================================================================
+// XCD-resident runs of unparameterized steps (256 x 256).
+//
+// The three-launch step above moves ~18 MB per member-step because every row <-> column exchange of the 2-D FFTs and
+// the spectral state go through HBM.  Here ONE persistent workgroup per CU is launched; the 32 workgroups that find
+// themselves on the same XCD (HW_REG_XCC_ID, read at run time — a fact about where they run, not an assumption about
+// dispatch) form a TEAM that owns one member at a time:
+//   * the member's spectral state (qh and the two tendencies of the AB3 history) lives in the team's REGISTERS for a
+//     whole run of K steps — workgroup r owns the 8 rows of mirror pairs 4r..4r+3 and the 8 columns 8r..8r+7 — so HBM is
+//     touched once per run (load + store of 3 x 1.06 MB per member), not once per step;
+//   * the two exchanges of a step (3 fields after the inverse-x pass, 2 fields after the forward-y pass) go through ONE
+//     3.2 MB buffer per team that stays in the XCD's 4 MB L2: plain stores (the vector L1 is write-through) drained with
+//     vmcnt(0) before the team barrier, consumer loads with sc1 (L1 bypass).  Both ends share one L2 by construction;
+//   * the forward-x pass + tendency + AB3 step of step n and the build + inverse-x pass of step n+1 touch the same rows
+//     of the same workgroup, so a step costs TWO team barriers (per-XCD counter, bounded spins).
+// A census at first use (8 teams x 32 workgroups, all resident) decides whether the path is available; otherwise, and
+// for parameterized / diagnostic steps and other grid sizes, the three-launch step runs.
+// ================================================================================================
+struct TeamCtl {
+    unsigned arrived, err, pad[30];
+    unsigned team_n[8][32];      // [x][0]: workgroups registered on XCD x
+    unsigned bar[8][32];         // [x][0]: arrive counter of team x
+    unsigned long long stamps[32];   // -DQGX_TEAM_STAMPS: phase timeline of one workgroup (10 ns ticks)
+};
+#ifdef QGX_TEAM_STAMPS
+#define TEAM_STAMP(i) do { if (tid == 0 && rank == 0 && x == 0 && b == x && s == 3) c->stamps[i] = wall_clock64(); } while (0)
+#else
+#define TEAM_STAMP(i) do { } while (0)
+#endif
+
+struct TeamArgs {
+    const double2 *qh_src, *p_src, *pp_src;
+    double2 *qh_dst, *p_dst, *pp_dst;
+    double2 *X;                  // team x works in zbuf slot x: ZF fields of N rows at pitch ZP
+    TeamCtl *ctl;
+    int nsteps, ablevel0, ZP, census_only;
+    double c[3][3];              // (dt1, dt2, dt3) of AB level 0, 1, 2
+};
+
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned team_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
+
+template <int K>
+__device__ __forceinline__ void team_load_sc1(double2 (&v)[K], const double2 *const (&p)[K]) {
+    v2d_t w[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[i]) : "v"(p[i]) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < K; ++i) v[i] = make_double2(w[i].x, w[i].y);
+}
+
+constexpr int TEAM_NT = 512, TEAM_WG = 32, TEAM_SPIN = 1 << 21;
+
+// every wave's stores reach L2, the workgroup arrives, lane 0 waits for the team.  false: timed out (flag raised)
+__device__ __forceinline__ bool team_barrier(unsigned *ctr, unsigned target, TeamCtl *c, int *ok_lds) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, good = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > TEAM_SPIN) { atomicExch(&c->err, 1u); good = 0; break; }
+        }
+        *ok_lds = good;
+    }
+    __syncthreads();
+    return *ok_lds != 0;
+}
+
+struct TeamState { double2 q0, q1, p0, p1, pp0, pp1; };
+constexpr int TEAM_NTAB = 6;                                   // per-element tables in LDS: a00 a01 a10 a11 filtr wv2
+
+template <int NN>
+__global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a) {
+    constexpr int N = NN, NK = N / 2 + 1, LD = N + 1, sz = N * NK, NT = TEAM_NT;
+    constexpr int RW = N / TEAM_WG;                  // rows (and columns) per workgroup: 8
+    constexpr int HALF = N / 2;                      // columns 0..HALF-1 live in registers, column HALF in LDS
+    constexpr int SL = RW * HALF / NT;               // register slots per thread: 2
+    static_assert(RW * HALF % NT == 0 && RW % 2 == 0, "team tiling");
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    int *pos = reinterpret_cast<int *>(L + (size_t)3 * RW * LD);
+    double2 *twl = reinterpret_cast<double2 *>(pos + N);
+    double2 *qsc = twl + N;                                        // [RW][2 columns][2 layers]
+    TeamState *nst = reinterpret_cast<TeamState *>(qsc + RW * 4);  // [RW]  state of the Nyquist column (i = N/2)
+    double *tab = reinterpret_cast<double *>(nst + RW);            // [TEAM_NTAB][SL * NT + RW]  tables of my elements, by slot
+    double *kkl = tab + TEAM_NTAB * (SL * NT + RW);                // [NK]
+    double *lll = kkl + NK + 1;                                    // [RW]  l of my rows
+    int *flags = reinterpret_cast<int *>(lll + RW);                // [0] barrier ok, [1] xcc, [2] rank, [3] teams ok
+    const int tid = threadIdx.x;
+    TeamCtl *c = a.ctl;
+
+    // ---- census: who shares my XCD ----
+    if (tid == 0) {
+        const unsigned x = team_xcc_id();
+        flags[1] = (int)x;
+        flags[2] = (int)atomicAdd(&c->team_n[x][0], 1u);
+        __hip_atomic_fetch_add(&c->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0, good = 1;
+        while (__hip_atomic_load(&c->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > TEAM_SPIN) { atomicExch(&c->err, 2u); good = 0; break; }
+        }
+        if (good)
+            for (int t = 0; t < 8; ++t)
+                if (__hip_atomic_load(&c->team_n[t][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != TEAM_WG) good = 0;
+        if (!good) atomicCAS(&c->err, 0u, 3u);
+        flags[3] = good;
+    }
+    for (int t = tid; t < N; t += NT) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
+    __syncthreads();
+    if (!flags[3] || a.census_only) return;
+    const int x = flags[1], rank = flags[2];
+    unsigned *ctr = &c->bar[x][0];
+    unsigned phase = 0;
+    const int p0 = rank * (RW / 2), c0 = rank * RW;
+    const size_t fz = (size_t)a.ZP * N;
+    double2 *X = a.X + (size_t)x * ZF * fz;
+    const int ZP = a.ZP;
+
+    // ---- element slots of this thread, tables of the rows this workgroup owns for the whole launch (LDS) ----
+    // slot t = tid + e * NT owns column i = 16 a + b of local row rl, with a = t & 7, rl = (t >> 3) & 7, b = t >> 6: eight
+    // consecutive lanes address eight consecutive digit-reversed positions pos[i] = 16 b + a (and N - i likewise), so the
+    // scattered LDS accesses of the build / tendency phases run 128 contiguous bytes per eight lanes; the Nyquist column
+    // (slot index SL * NT + rl) belongs to lanes 0..7 of wave 1, the self-conjugate column 0 to wave 0
+    constexpr int NE = SL * NT + RW;
+    static_assert(N == 256, "slot mapping is written for 256 = 16 x 16");
+    int el_i[SL], el_r[SL], el_j[SL];
+#pragma unroll
+    for (int e = 0; e < SL; ++e) {
+        const int t = tid + e * NT;
+        el_i[e] = 16 * (t & 7) + (t >> 6); el_r[e] = (t >> 3) & 7;
+        el_j[e] = pair_row(p0 + (el_r[e] >> 1), el_r[e] & 1, N);
+        const int idx = el_j[e] * NK + el_i[e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tab[q * NE + t] = d.a[(size_t)q * sz + idx];
+        tab[4 * NE + t] = d.filtr[idx];
+        tab[5 * NE + t] = d.wv2[idx];
+    }
+    const bool nyq = tid >= 64 && tid < 64 + RW;
+    const int nr = tid - 64;                                   // local row of my Nyquist element
+    if (nyq) {
+        const int idx = pair_row(p0 + (nr >> 1), nr & 1, N) * NK + HALF, t = SL * NT + nr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tab[q * NE + t] = d.a[(size_t)q * sz + idx];
+        tab[4 * NE + t] = d.filtr[idx];
+        tab[5 * NE + t] = d.wv2[idx];
+    }
+    for (int t = tid; t < NK; t += NT) kkl[t] = d.kk[t];
+    if (tid < RW) lll[tid] = d.ll[pair_row(p0 + (tid >> 1), tid & 1, N)];
+    __syncthreads();
+
+    // one element of the build phase: spectra of (u_k + i v_k) and (q_1 + i q_2), Hermitian-extended, into the LDS lines
+    auto build = [&](const TeamState &st, int i, int rl, int te) {
+        const int rm = (p0 + (rl >> 1)) == 0 ? rl : (rl ^ 1);
+        const bool selfc = (i == 0 || 2 * i == N);
+        const double2 q0 = st.q0, q1 = st.q1;
+        double2 q0m = q0, q1m = q1;
+        const int tm = i == 0 ? (rm << 3) : SL * NT + rm;      // slot of the mirror row's element (self-conjugate columns)
+        if (selfc) {
+            const int ic = i == 0 ? 0 : 1;
+            q0m = qsc[(rm * 2 + ic) * 2]; q1m = qsc[(rm * 2 + ic) * 2 + 1];
+        }
+        const double kx = kkl[i], ly = lll[rl], lm = lll[rm];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double a0 = tab[(2 * k) * NE + te], a1 = tab[(2 * k + 1) * NE + te];
+            const double2 ph = make_double2(a0 * q0.x + a1 * q1.x, a0 * q0.y + a1 * q1.y);
+            double2 uh = make_double2(ly * ph.y, -ly * ph.x);
+            double2 vh = make_double2(-kx * ph.y, kx * ph.x);
+            if (selfc) {
+                const double m0 = tab[(2 * k) * NE + tm], m1 = tab[(2 * k + 1) * NE + tm];
+                const double2 pm = make_double2(m0 * q0m.x + m1 * q1m.x, m0 * q0m.y + m1 * q1m.y);
+                const double2 um = make_double2(lm * pm.y, -lm * pm.x);
+                const double2 vm = make_double2(-kx * pm.y, kx * pm.x);
+                uh = make_double2(0.5 * (uh.x + um.x), 0.5 * (uh.y - um.y));
+                vh = make_double2(0.5 * (vh.x + vm.x), 0.5 * (vh.y - vm.y));
+            }
+            L[(rl * 3 + k) * LD + pos[i]] = make_double2((uh.x - vh.y) * d.invN2, (uh.y + vh.x) * d.invN2);
+            if (!selfc) L[(rm * 3 + k) * LD + pos[N - i]] = make_double2((uh.x + vh.y) * d.invN2, (vh.x - uh.y) * d.invN2);
+        }
+        double2 A = q0, Bq = q1;
+        if (selfc) {
+            A = make_double2(0.5 * (A.x + q0m.x), 0.5 * (A.y - q0m.y));
+            Bq = make_double2(0.5 * (Bq.x + q1m.x), 0.5 * (Bq.y - q1m.y));
+        }
+        L[(rl * 3 + 2) * LD + pos[i]] = make_double2((A.x - Bq.y) * d.invN2, (A.y + Bq.x) * d.invN2);
+        if (!selfc) L[(rm * 3 + 2) * LD + pos[N - i]] = make_double2((A.x + Bq.y) * d.invN2, (Bq.x - A.y) * d.invN2);
+    };
+
+    // one element of the tendency phase: unpack (uq_k, vq_k) from the transformed lines, tendency, AB3 + filter, rotate
+    auto tend = [&](TeamState &st, int i, int rl, int te, double dt1, double dt2, double dt3) {
+        const int rm = (p0 + (rl >> 1)) == 0 ? rl : (rl ^ 1);
+        const int im = i == 0 ? 0 : N - i;
+        const double kx = kkl[i], ly = lll[rl];
+        const double2 q0 = st.q0, q1 = st.q1;
+        double2 tn[2], qn[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double2 A = L[(rl * 2 + k) * LD + pos[i]], C = L[(rm * 2 + k) * LD + pos[im]];
+            const double2 uqh = make_double2(0.5 * (A.x + C.x), 0.5 * (A.y - C.y));
+            const double2 vqh = make_double2(0.5 * (A.y + C.y), -0.5 * (A.x - C.x));
+            const double a0 = tab[(2 * k) * NE + te], a1 = tab[(2 * k + 1) * NE + te];
+            const double2 ph = make_double2(a0 * q0.x + a1 * q1.x, a0 * q0.y + a1 * q1.y);
+            const double kq = kx * d.Qy[k];
+            double tx = (kx * uqh.y + ly * vqh.y + kq * ph.y);
+            double ty = -(kx * uqh.x + ly * vqh.x + kq * ph.x);
+            if (k == 1 && d.rek != 0.0) {
+                const double f = d.rek * tab[5 * NE + te];
+                tx += f * ph.x;
+                ty += f * ph.y;
+            }
+            tx += 0.0; ty += 0.0;                    // the (absent) forcing of k_l_rows_fwd_tend
+            const double2 p = k == 0 ? st.p0 : st.p1, pp = k == 0 ? st.pp0 : st.pp1;
+            const double2 qk = k == 0 ? q0 : q1;
+            const double f = tab[4 * NE + te];
+            tn[k] = make_double2(tx, ty);
+            qn[k] = make_double2(f * (qk.x + dt1 * tx + dt2 * p.x + dt3 * pp.x),
+                                 f * (qk.y + dt1 * ty + dt2 * p.y + dt3 * pp.y));
+        }
+        st.pp0 = st.p0; st.pp1 = st.p1;
+        st.p0 = tn[0]; st.p1 = tn[1];
+        st.q0 = qn[0]; st.q1 = qn[1];
+    };
+
+    for (int b = x; b < d.B; b += 8) {
+        const size_t mo = (size_t)b * 2 * sz;
+        TeamState S[SL];
+#pragma unroll
+        for (int e = 0; e < SL; ++e) {
+            const size_t o = mo + (size_t)el_j[e] * NK + el_i[e];
+            S[e] = TeamState{a.qh_src[o], a.qh_src[o + sz], a.p_src[o], a.p_src[o + sz], a.pp_src[o], a.pp_src[o + sz]};
+        }
+        if (nyq) {
+            const size_t o = mo + (size_t)pair_row(p0 + (nr >> 1), nr & 1, N) * NK + HALF;
+            nst[nr] = TeamState{a.qh_src[o], a.qh_src[o + sz], a.p_src[o], a.p_src[o + sz], a.pp_src[o], a.pp_src[o + sz]};
+        }
+        for (int s = 0; s <= a.nsteps; ++s) {
+            // (addresses derive from an opaque copy of the thread id: hoisted out of the step loop they would pin ~80 registers)
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            if (s > 0) {
+                // ---- rows: forward along x of the two product fields, tendency, AB3 step ----
+                TEAM_STAMP(0);
+                {
+                    constexpr int KL = 2 * RW * N / NT;            // 8 loads per thread
+                    double2 v[KL];
+                    const double2 *pp[KL];
+#pragma unroll
+                    for (int n = 0; n < KL; ++n) {
+                        const int t = tl + n * NT, e = t % N, line = t / N;
+                        const int j = pair_row(p0 + (line >> 2), (line >> 1) & 1, N);
+                        pp[n] = X + (size_t)(line & 1) * fz + (size_t)j * ZP + e;
+                    }
+                    team_load_sc1<KL>(v, pp);
+#pragma unroll
+                    for (int n = 0; n < KL; ++n) {
+                        const int t = tl + n * NT;
+                        L[(t / N) * LD + t % N] = v[n];
+                    }
+                }
+                __syncthreads();
+                TEAM_STAMP(1);
+                fft_lines_fwd_t<NN, NN>(L, 2 * RW, LD, 1, twl);
+                TEAM_STAMP(2);
+                const int lev = a.ablevel0 + s - 1 > 2 ? 2 : a.ablevel0 + s - 1;
+                const double dt1 = a.c[lev][0], dt2 = a.c[lev][1], dt3 = a.c[lev][2];
+#pragma unroll
+                for (int e = 0; e < SL; ++e) tend(S[e], el_i[e], el_r[e], tid + e * NT, dt1, dt2, dt3);
+                if (nyq) {
+                    TeamState st = nst[nr];
+                    tend(st, HALF, nr, SL * NT + nr, dt1, dt2, dt3);
+                    nst[nr] = st;
+                }
+                __syncthreads();
+                TEAM_STAMP(3);
+                if (s == a.nsteps) break;
+            }
+            // ---- rows: build the three packed spectra from qh, inverse along x, publish the rows ----
+#pragma unroll
+            for (int e = 0; e < SL; ++e)
+                if (el_i[e] == 0) { qsc[(el_r[e] * 2) * 2] = S[e].q0; qsc[(el_r[e] * 2) * 2 + 1] = S[e].q1; }
+            if (nyq) { qsc[(nr * 2 + 1) * 2] = nst[nr].q0; qsc[(nr * 2 + 1) * 2 + 1] = nst[nr].q1; }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < SL; ++e) build(S[e], el_i[e], el_r[e], tid + e * NT);
+            if (nyq) build(nst[nr], HALF, nr, SL * NT + nr);
+            __syncthreads();
+            TEAM_STAMP(4);
+            fft_lines_inv_t<NN, NN>(L, 3 * RW, LD, 1, twl);
+            TEAM_STAMP(5);
+#pragma unroll
+            for (int n = 0; n < 3 * RW * N / NT; ++n) {
+                const int t = tl + n * NT, e = t % N, line = t / N;
+                const int rl = line / 3, f = line - rl * 3;
+                const int j = pair_row(p0 + (rl >> 1), rl & 1, N);
+                X[(size_t)f * fz + (size_t)j * ZP + e] = L[line * LD + e];
+            }
+            TEAM_STAMP(6);
+            if (!team_barrier(ctr, ++phase * TEAM_WG, c, flags)) return;
+            TEAM_STAMP(7);
+            // ---- columns: inverse along y of the three fields, advection products, forward along y of two ----
+            {
+                constexpr int KL = 3 * RW * N / NT;                // 12 loads per thread
+                double2 v[KL];
+                const double2 *pp[KL];
+#pragma unroll
+                for (int n = 0; n < KL; ++n) {
+                    const int t = tl + n * NT;
+                    const int k = t / (RW * N), t2 = t - k * RW * N, cc = t2 & (RW - 1), r = ((t2 >> 3) & 1) * (N / 2) + (t2 >> 4);
+                    pp[n] = X + (size_t)k * fz + (size_t)r * ZP + c0 + cc;
+                }
+                team_load_sc1<KL>(v, pp);
+#pragma unroll
+                for (int n = 0; n < KL; ++n) {
+                    const int t = tl + n * NT;
+                    const int k = t / (RW * N), t2 = t - k * RW * N, cc = t2 & (RW - 1), r = ((t2 >> 3) & 1) * (N / 2) + (t2 >> 4);
+                    L[(k * RW + cc) * LD + pos[r]] = v[n];
+                }
+            }
+            __syncthreads();
+            TEAM_STAMP(8);
+            fft_lines_inv_t<NN, NN>(L, 3 * RW, LD, 1, twl);
+            TEAM_STAMP(9);
+#pragma unroll
+            for (int n = 0; n < 2 * RW * N / NT; ++n) {
+                const int t = tl + n * NT;
+                const int k = t / (RW * N), t2 = t - k * RW * N, r = t2 & (N - 1), cc = t2 >> 8;   // lanes along the line
+                const double2 uv = L[(k * RW + cc) * LD + r];
+                const double2 qq = L[(2 * RW + cc) * LD + r];
+                const double qv = k == 0 ? qq.x : qq.y;
+                L[(k * RW + cc) * LD + r] = make_double2((uv.x + d.U[k]) * qv, uv.y * qv);
+            }
+            __syncthreads();
+            TEAM_STAMP(10);
+            fft_lines_fwd_t<NN, NN>(L, 2 * RW, LD, 1, twl);
+            TEAM_STAMP(11);
+#pragma unroll
+            for (int n = 0; n < 2 * RW * N / NT; ++n) {
+                const int t = tl + n * NT;
+                const int k = t / (RW * N), t2 = t - k * RW * N, cc = t2 & (RW - 1), r = ((t2 >> 3) & 1) * (N / 2) + (t2 >> 4);
+                X[(size_t)k * fz + (size_t)r * ZP + c0 + cc] = L[(k * RW + cc) * LD + pos[r]];
+            }
+            TEAM_STAMP(12);
+            if (!team_barrier(ctr, ++phase * TEAM_WG, c, flags)) return;
+            TEAM_STAMP(13);
+        }
+        // ---- the run is over for this member: state back to memory ----
+#pragma unroll
+        for (int e = 0; e < SL; ++e) {
+            const size_t o = mo + (size_t)el_j[e] * NK + el_i[e];
+            a.qh_dst[o] = S[e].q0; a.qh_dst[o + sz] = S[e].q1;
+            a.p_dst[o] = S[e].p0; a.p_dst[o + sz] = S[e].p1;
+            a.pp_dst[o] = S[e].pp0; a.pp_dst[o + sz] = S[e].pp1;
+        }
+        if (nyq) {
+            const size_t o = mo + (size_t)pair_row(p0 + (nr >> 1), nr & 1, N) * NK + HALF;
+            const TeamState st = nst[nr];
+            a.qh_dst[o] = st.q0; a.qh_dst[o + sz] = st.q1;
+            a.p_dst[o] = st.p0; a.p_dst[o + sz] = st.p1;
+            a.pp_dst[o] = st.pp0; a.pp_dst[o + sz] = st.pp1;
+        }
+        __syncthreads();
+    }
+}
+
+static size_t team_lds(int N) {
+    const int RW = N / TEAM_WG;
+    const int NK = N / 2 + 1;
+    return (size_t)3 * RW * (N + 1) * 16 + (size_t)N * 4 + (size_t)N * 16 + (size_t)RW * 4 * 16 + (size_t)RW * sizeof(TeamState) +
+           (size_t)TEAM_NTAB * (2 * TEAM_NT + RW) * 8 + (size_t)(NK + 1) * 8 + (size_t)RW * 8 + 64;
+}
+
+// 1: the device runs 8 teams of 32 co-resident workgroups (census passed), 0: it does not.  Decided once per model.
+int large_team_available(qgx_model *m, hipStream_t st) {
+    const bool off = getenv("QGX_LARGE_NO_TEAM") != nullptr;                 // A/B aid (read per call: tests toggle it)
+    if (off || m->N != 256 || m->B < 1) return 0;
+    if (m->team_state != 0) return m->team_state > 0;
+    m->team_state = -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, m->cfg.device) != hipSuccess || prop.multiProcessorCount != 8 * TEAM_WG) return 0;
+    if (hipMalloc(&m->team_ctl, sizeof(TeamCtl)) != hipSuccess) { m->team_ctl = nullptr; return 0; }
+    if (hipFuncSetAttribute((const void *)k_l_team_steps<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024 - 512) != hipSuccess) return 0;
+    TeamArgs a{};
+    a.ctl = (TeamCtl *)m->team_ctl;
+    a.census_only = 1;
+    a.ZP = m->N + large_zpad();
+    if (hipMemsetAsync(m->team_ctl, 0, sizeof(TeamCtl), st) != hipSuccess) return 0;
+    hipLaunchKernelGGL((k_l_team_steps<256>), dim3(8 * TEAM_WG), dim3(TEAM_NT), team_lds(256), st, m->d, a);
+    TeamCtl h;
+    if (hipMemcpyAsync(&h, m->team_ctl, sizeof(TeamCtl), hipMemcpyDeviceToHost, st) != hipSuccess) return 0;
+    if (hipStreamSynchronize(st) != hipSuccess) return 0;
+    if (h.err == 0) m->team_state = 1;
+    return m->team_state > 0;
+}
+
+// a finished run must have raised no flag (barrier time-out, census changed under our feet): loud, not silent
+int large_team_check(qgx_model *m, hipStream_t st) {
+    if (!m->team_pending) return QGX_OK;
+    m->team_pending = false;
+    TeamCtl h;
+    QGX_HIP(hipMemcpyAsync(&h, m->team_ctl, sizeof(TeamCtl), hipMemcpyDeviceToHost, st));
+    QGX_HIP(hipStreamSynchronize(st));
+#ifdef QGX_TEAM_STAMPS
+    {
+        static const char *names[] = {"C load rows", "C fft fwd x", "C tendency", "A build", "A fft inv x", "A store rows", "barrier 1",
+                                      "B load cols", "B fft inv y", "B products", "B fft fwd y", "B store cols", "barrier 2"};
+        fprintf(stderr, "team step timeline (workgroup 0 of team 0, step 3; us):");
+        for (int i = 0; i < 13; ++i) fprintf(stderr, " %s %.2f |", names[i], (double)(long long)(h.stamps[i + 1] - h.stamps[i]) / 100.0);
+        fprintf(stderr, " total %.2f\n", (double)(long long)(h.stamps[13] - h.stamps[0]) / 100.0);
+    }
+#endif
+    if (h.err != 0) {
+        m->team_state = -1;
+        set_error("XCD-resident step kernel raised flag %u (1: team barrier timed out, 2: workgroups not co-resident, "
+                  "3: census changed); the model state is undefined", h.err);
+        return QGX_ERR_HIP;
+    }
+    return QGX_OK;
+}
+
+// K consecutive unparameterized steps without diagnostics output; coef[level] = (dt1, dt2, dt3)
+int large_team_steps(qgx_model *m, int K, int ablevel0, const double coef[3][3], const double2 *qh_src, double2 *qh_dst,
+                     const double2 *p_src, const double2 *pp_src, double2 *p_dst, double2 *pp_dst, hipStream_t st) {
+    int rc = large_team_check(m, st);
+    if (rc) return rc;
+    TeamArgs a{};
+    a.qh_src = qh_src; a.qh_dst = qh_dst; a.p_src = p_src; a.pp_src = pp_src; a.p_dst = p_dst; a.pp_dst = pp_dst;
+    a.X = m->zbuf; a.ctl = (TeamCtl *)m->team_ctl;
+    a.nsteps = K; a.ablevel0 = ablevel0; a.ZP = m->N + large_zpad(); a.census_only = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a.c[i][j] = coef[i][j];
+    QGX_HIP(hipMemsetAsync(m->team_ctl, 0, sizeof(TeamCtl), st));
+    hipLaunchKernelGGL((k_l_team_steps<256>), dim3(8 * TEAM_WG), dim3(TEAM_NT), team_lds(256), st, m->d, a);
+    QGX_HIP(hipGetLastError());
+    m->team_pending = true;
+    m->q_stale = true;
+    return QGX_OK;
+}
+
 }  // namespace qgx

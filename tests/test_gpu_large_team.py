@@ -1,0 +1,113 @@
+"""XCD-resident runs of unparameterized 256 x 256 steps (spectral_large.hip, k_l_team_steps): the same results as the
+three-launch step and as the oracle; availability census; runs interrupted by the diagnostics cadence."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qg_ref
+
+pytestmark = pytest.mark.gpu
+
+F64_TOL = 2e-13
+
+
+def _rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(b)).max()
+
+
+def _eddy_like_q(rs, B, N):
+    k = np.fft.rfftfreq(N, 1.0 / N)
+    l = np.fft.fftfreq(N, 1.0 / N)
+    mask = np.sqrt(k[None, :] ** 2 + l[:, None] ** 2) < (2. / 3.) * (N // 2)
+    q = rs.randn(B, 2, N, N) * np.array([8e-6, 1e-6])[None, :, None, None]
+    return np.fft.irfftn(np.fft.rfftn(q, axes=(-2, -1)) * mask, axes=(-2, -1)) * 3.0
+
+
+def _engine(B, **kw):
+    import pyqg_generative_amd as qa
+    return qa.EnsembleEngine(nx=256, n_members=B, device=0, **kw)
+
+
+class _no_team:
+    def __enter__(self):
+        os.environ['QGX_LARGE_NO_TEAM'] = '1'
+
+    def __exit__(self, *a):
+        del os.environ['QGX_LARGE_NO_TEAM']
+
+
+@pytest.mark.parametrize('B', [11, 3])
+def test_runs_equal_the_three_launch_step_and_the_oracle(B):
+    """chunks of steps from a cold start (Euler -> AB2 -> AB3 inside the first run) against single steps of the
+    three-launch path (same arithmetic, different kernels) and against the CPU oracle"""
+    import pyqg_generative_amd._lib as L
+    q0 = _eddy_like_q(np.random.RandomState(77), B, 256)
+    e1, e2 = _engine(B, dt=3600.), _engine(B, dt=3600.)
+    e1.set_q(q0)
+    e2.set_q(q0)
+    for chunk in (7, 1, 4):
+        e1.step(chunk)                       # run of chunk - 1 steps + the refreshing step
+        with _no_team():
+            e2.step(chunk)
+        for f in (L.F_QH, L.F_DQHDT, L.F_DQHDT_PP, L.F_Q, L.F_U, L.F_V, L.F_PH):
+            a, b = e1.get(f), e2.get(f)
+            assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-13, (chunk, f)
+    assert e1.tc == e2.tc == 12
+    refs = []
+    for b in range(min(B, 2)):
+        m = qg_ref.QGModelRef(nx=256, dt=3600.)
+        m.set_q(q0[b])
+        for _ in range(12):
+            m._step_forward()
+        refs.append(m)
+    qh = e1.get(L.F_QH).cpu().numpy()
+    dq = e1.get(L.F_DQHDT).cpu().numpy()
+    for b, m in enumerate(refs):
+        assert _rel(qh[b], m.qh) < F64_TOL * 12
+        assert _rel(dq[b], m.dqhdt_p) < 1e-10
+    ke, cfl = e1.status()
+    assert abs(ke[0] - refs[0]._calc_ke()) < 1e-11 * refs[0]._calc_ke()
+    e1.close()
+    e2.close()
+
+
+def test_runs_respect_the_diagnostics_cadence():
+    """time-averaged diagnostics accumulate at the same steps with and without the run kernel"""
+    import pyqg_generative_amd._lib as L
+    B = 8
+    q0 = _eddy_like_q(np.random.RandomState(78), B, 256)
+    out = []
+    for team in (True, False):
+        e = _engine(B, dt=3600.)
+        e.set_q(q0)
+        e.diag_config(0, 5)
+        if team:
+            e.step(23)
+        else:
+            with _no_team():
+                e.step(23)
+        out.append((e.diag('KEspec').cpu().numpy(), e.diag('KEflux').cpu().numpy(), e.get(L.F_QH).cpu().numpy(),
+                    e.diag_count))
+        e.close()
+    assert out[0][3] == out[1][3] == 4
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert _rel(a, b) < 1e-12
+
+
+def test_long_run_is_deterministic_and_flag_free():
+    """two identical 100-step runs are bit-identical (no stale or torn exchange reads), and the kernel raised no flag"""
+    import pyqg_generative_amd._lib as L
+    B = 16
+    q0 = _eddy_like_q(np.random.RandomState(79), B, 256)
+    res = []
+    for _ in range(2):
+        e = _engine(B, dt=3600.)
+        e.set_q(q0)
+        e.step(100, refresh_diag=False)
+        res.append(e.get(L.F_QH).clone())
+        ke, cfl = e.status()
+        assert np.isfinite(ke).all()
+        e.close()
+    assert torch.equal(res[0], res[1])
