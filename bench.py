@@ -266,7 +266,7 @@ def leg_config4(qa, device, K, W):
            'steps': K, 'ms_per_step': step_ms, 'coarsegrain_ms': 1e3 * el - step_ms * K,
            'value_at_reference_cadence': B * snap / (step_ms * 1e-3 * snap + (el - step_ms * 1e-3 * K)),
            'cadence_note': f'reference cadence: one coarse-grain per {snap} steps',
-           'roofline': {'bound': 'hbm', 'kernel': 'spectral step (5 launches of spectral_large.hip per step)',
+           'roofline': {'bound': 'hbm', 'kernel': 'spectral step (spectral_large.hip: XCD-resident run kernel k_l_team_steps + one three-launch step per call)',
                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': pmc_traffic('pmc_traffic_config4.json', {'nx': N, 'members': B}),
                         'bytes_per_step': bytes_step, 'avg_step_ms': step_ms,
