@@ -38,7 +38,7 @@ class _no_team:
         del os.environ['QGX_LARGE_NO_TEAM']
 
 
-@pytest.mark.parametrize('B', [11, 3])
+@pytest.mark.parametrize('B', [11, 3, 1, 9])
 def test_runs_equal_the_three_launch_step_and_the_oracle(B):
     """chunks of steps from a cold start (Euler -> AB2 -> AB3 inside the first run) against single steps of the
     three-launch path (same arithmetic, different kernels) and against the CPU oracle"""
@@ -111,3 +111,27 @@ def test_long_run_is_deterministic_and_flag_free():
         assert np.isfinite(ke).all()
         e.close()
     assert torch.equal(res[0], res[1])
+
+
+def test_state_changes_between_runs_are_honoured():
+    """set_q / reset between runs: the run kernel starts from the model's current state and AB level"""
+    import pyqg_generative_amd._lib as L
+    B = 8
+    rs = np.random.RandomState(80)
+    q0, q1 = _eddy_like_q(rs, B, 256), _eddy_like_q(rs, B, 256)
+    e1, e2 = _engine(B, dt=3600.), _engine(B, dt=3600.)
+    for e, team in ((e1, True), (e2, False)):
+        ctx = _no_team() if not team else None
+        if ctx:
+            ctx.__enter__()
+        e.set_q(q0)
+        e.step(6, refresh_diag=False)
+        e.set_q(q1)                        # pyqg's q setter keeps the AB history and level
+        e.step(5, refresh_diag=False)
+        if ctx:
+            ctx.__exit__()
+    for f in (L.F_QH, L.F_DQHDT, L.F_DQHDT_PP):
+        assert _rel(e1.get(f).cpu().numpy(), e2.get(f).cpu().numpy()) < 1e-13
+    assert e1.tc == e2.tc == 11
+    e1.close()
+    e2.close()
