@@ -76,7 +76,6 @@ class QGModel:
         self._eng = EnsembleEngine(nx=nx, n_members=n_members, device=device, L=L, dt=dt, rek=rek,
                                    delta=delta, beta=beta, rd=rd, U1=U1, U2=U2, H1=H1,
                                    filterfac=filterfac)
-        self._scratch = None
         self._init_grid()
         self.t = 0.
         self.taveints = math.ceil(self.taveint / self.dt)
@@ -181,33 +180,25 @@ class QGModel:
     def q_device(self):
         return self._eng.get(_lib.F_Q)
 
-    # ---- transforms on (…,2,N,N) / (…,2,N,NK) host arrays, executed on the device ----
-    def _scratch_engine(self, B):
-        if self._scratch is None or self._scratch.B != B:
-            self._scratch = EnsembleEngine(nx=self.nx, n_members=B, device=self._eng.device.index or 0)
-        return self._scratch
-
+    # ---- pyqg's m.fft / m.ifft over the last two axes, executed on the device ----------
+    # numpy in -> numpy out (pyqg's contract); a CUDA tensor in -> a CUDA tensor out, no host round trip.  The transforms
+    # run on the plans of tools.operators.Dev (an LRU cache keyed by grid size and field count), so calls inside loops
+    # — the reference's `divergence` transforms field by field — neither allocate engines nor leak them.
     def fft(self, x):
-        x = np.asarray(x, dtype='float64')
-        lead = x.shape[:-2]
-        flat = x.reshape((-1, self.ny, self.nx))
-        n = flat.shape[0]
-        pad = flat if n % 2 == 0 else np.concatenate([flat, np.zeros_like(flat[:1])])
-        s = self._scratch_engine(pad.shape[0] // 2)
-        s.set_q(pad.reshape(-1, 2, self.ny, self.nx))
-        out = s.get(_lib.F_QH).cpu().numpy().reshape(-1, self.nl, self.nk)[:n]
-        return out.reshape(lead + (self.nl, self.nk))
+        from .tools.operators import Dev
+        on_dev = torch.is_tensor(x)
+        xt = x.to(torch.float64) if on_dev else torch.as_tensor(np.asarray(x, dtype='float64'), device=self._eng.device)
+        lead = tuple(xt.shape[:-2])
+        out = Dev.rfft2(xt.reshape((-1, self.ny, self.nx))).reshape(lead + (self.nl, self.nk))
+        return out if on_dev else out.cpu().numpy()
 
     def ifft(self, xh):
-        xh = np.asarray(xh, dtype='complex128')
-        lead = xh.shape[:-2]
-        flat = xh.reshape((-1, self.nl, self.nk))
-        n = flat.shape[0]
-        pad = flat if n % 2 == 0 else np.concatenate([flat, np.zeros_like(flat[:1])])
-        s = self._scratch_engine(pad.shape[0] // 2)
-        s.set_qh(pad.reshape(-1, 2, self.nl, self.nk))
-        out = s.get(_lib.F_Q).cpu().numpy().reshape(-1, self.ny, self.nx)[:n]
-        return out.reshape(lead + (self.ny, self.nx))
+        from .tools.operators import Dev
+        on_dev = torch.is_tensor(xh)
+        xt = xh.to(torch.complex128) if on_dev else torch.as_tensor(np.asarray(xh, dtype='complex128'), device=self._eng.device)
+        lead = tuple(xt.shape[:-2])
+        out = Dev.irfft2(xt.reshape((-1, self.nl, self.nk))).reshape(lead + (self.ny, self.nx))
+        return out if on_dev else out.cpu().numpy()
 
     # ---- dynamics -------------------------------------------------------------------
     def _invert(self):
@@ -323,5 +314,3 @@ class QGModel:
 
     def close(self):
         self._eng.close()
-        if self._scratch is not None:
-            self._scratch.close()

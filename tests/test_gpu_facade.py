@@ -58,6 +58,15 @@ def test_qgmodel_surface_matches_pyqg_conventions():
     x = rs.randn(2, N, N)
     np.testing.assert_allclose(m.fft(x), np.fft.rfftn(x, axes=(-2, -1)), atol=1e-11)
     np.testing.assert_allclose(m.ifft(m.fft(x[0])), x[0], atol=1e-12)
+    # device tensors stay on the device; calls of changing shape inside a loop reuse cached plans (no engines leak)
+    from pyqg_generative_amd.tools.operators import Dev
+    xd = torch.as_tensor(rs.randn(3, 2, N, N), device='cuda')
+    for lead in ((3, 2), (6,), (1,), (3, 2), (5,)):
+        xh = m.fft(xd.reshape(-1, N, N)[:int(np.prod(lead))].reshape(lead + (N, N)))
+        assert torch.is_tensor(xh) and xh.is_cuda and tuple(xh.shape) == lead + (N, N // 2 + 1)
+        back = m.ifft(xh)
+        assert back.is_cuda and torch.allclose(back, xd.reshape(-1, N, N)[:int(np.prod(lead))].reshape(lead + (N, N)), atol=1e-12)
+    assert len(Dev._plans) <= Dev.MAX_PLANS
     m.set_q1q2(q[0], 0 * q[1])
     assert np.abs(m.q[1]).max() == 0
     m.close()
