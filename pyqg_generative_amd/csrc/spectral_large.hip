@@ -760,14 +760,14 @@ typedef double v2d_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned team_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
 
-template <int K>
-__device__ __forceinline__ void team_load_sc1(double2 (&v)[K], const double2 *const (&p)[K]) {
-    v2d_t w[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(w[i]) : "v"(p[i]) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < K; ++i) v[i] = make_double2(w[i].x, w[i].y);
+// exchange-buffer loads: buffer loads with the sc1 bit (served by L2, never by this CU's vector L1, whose lines other
+// workgroups have rewritten since) issued through the compiler's builtin, so that IT places the waits (hand-written asm
+// loads leave their destination registers unprotected until a later s_waitcnt)
+typedef unsigned int team_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 team_ld(__amdgpu_buffer_rsrc_t rs, size_t elem) {
+    const team_u4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(elem * sizeof(double2)), 0, 16);
+    return make_double2(__longlong_as_double(((unsigned long long)w.y << 32) | w.x),
+                        __longlong_as_double(((unsigned long long)w.w << 32) | w.z));
 }
 
 constexpr int TEAM_NT = 512, TEAM_WG = 32, TEAM_SPIN = 1 << 21;
@@ -807,7 +807,8 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
     double *tab = reinterpret_cast<double *>(nst + RW);            // [TEAM_NTAB][SL * NT + RW]  tables of my elements, by slot
     double *kkl = tab + TEAM_NTAB * (SL * NT + RW);                // [NK]
     double *lll = kkl + NK + 1;                                    // [RW]  l of my rows
-    int *flags = reinterpret_cast<int *>(lll + RW);                // [0] barrier ok, [1] xcc, [2] rank, [3] teams ok
+    int *ipos = reinterpret_cast<int *>(lll + RW);                 // [N]  frequency held at a digit-reversed position
+    int *flags = ipos + N;                                         // [0] barrier ok, [1] xcc, [2] rank, [3] teams ok
     const int tid = threadIdx.x;
     TeamCtl *c = a.ctl;
 
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
         if (!good) atomicCAS(&c->err, 0u, 3u);
         flags[3] = good;
     }
-    for (int t = tid; t < N; t += NT) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
+    for (int t = tid; t < N; t += NT) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; ipos[d.pos[t]] = t; }
     __syncthreads();
     if (!flags[3] || a.census_only) return;
     const int x = flags[1], rank = flags[2];
@@ -837,6 +838,7 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
     const int p0 = rank * (RW / 2), c0 = rank * RW;
     const size_t fz = (size_t)a.ZP * N;
     double2 *X = a.X + (size_t)x * ZF * fz;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, (int)(ZF * fz * sizeof(double2)), 0x00020000);
     const int ZP = a.ZP;
 
     // ---- element slots of this thread, tables of the rows this workgroup owns for the whole launch (LDS) ----
@@ -966,14 +968,12 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
                 {
                     constexpr int KL = 2 * RW * N / NT;            // 8 loads per thread
                     double2 v[KL];
-                    const double2 *pp[KL];
 #pragma unroll
                     for (int n = 0; n < KL; ++n) {
                         const int t = tl + n * NT, e = t % N, line = t / N;
                         const int j = pair_row(p0 + (line >> 2), (line >> 1) & 1, N);
-                        pp[n] = X + (size_t)(line & 1) * fz + (size_t)j * ZP + e;
+                        v[n] = team_ld(xrs, (size_t)(line & 1) * fz + (size_t)j * ZP + e);
                     }
-                    team_load_sc1<KL>(v, pp);
 #pragma unroll
                     for (int n = 0; n < KL; ++n) {
                         const int t = tl + n * NT;
@@ -1021,46 +1021,65 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
             if (!team_barrier(ctr, ++phase * TEAM_WG, c, flags)) return;
             TEAM_STAMP(7);
             // ---- columns: inverse along y of the three fields, advection products, forward along y of two ----
+            // 256 = 16 x 16: the first radix-16 pass of the inverse takes its operands straight from the exchange buffer
+            // and the last pass of the forward transform stores straight to it; between them the inverse's second pass,
+            // the products and the forward's first pass work on the same sixteen rows {b + 16 m} of a column in registers.
+            // LDS sees 4 sweeps of a line instead of 12, the phase 3 barriers instead of 9.
             {
-                constexpr int KL = 3 * RW * N / NT;                // 12 loads per thread
-                double2 v[KL];
-                const double2 *pp[KL];
+                const int cc = tl & 7, blk = (tl >> 3) & 15, k1 = tl >> 7;          // pass 1 / last pass: (field, column, block)
+                double2 v[16];
+                if (tl < 3 * RW * 16) {
 #pragma unroll
-                for (int n = 0; n < KL; ++n) {
-                    const int t = tl + n * NT;
-                    const int k = t / (RW * N), t2 = t - k * RW * N, cc = t2 & (RW - 1), r = ((t2 >> 3) & 1) * (N / 2) + (t2 >> 4);
-                    pp[n] = X + (size_t)k * fz + (size_t)r * ZP + c0 + cc;
+                    for (int m = 0; m < 16; ++m) v[m] = team_ld(xrs, (size_t)k1 * fz + (size_t)ipos[16 * blk + m] * ZP + c0 + cc);
+                    TEAM_STAMP(8);
+                    small_dft<16, false>(v);
+                    double2 *base = L + (k1 * RW + cc) * LD + 16 * blk;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) base[m] = v[m];
                 }
-                team_load_sc1<KL>(v, pp);
+                __syncthreads();
+                TEAM_STAMP(9);
+                // second pass of the inverse: tasks (field, column, b); the q field publishes its rows, (u, v) keep theirs
+                const int b2 = tl & 15, c2 = (tl >> 4) & 7, k2 = tl >> 7;
+                double2 *line2 = L + (k2 * RW + c2) * LD + b2;
+                if (tl < 3 * RW * 16) {
 #pragma unroll
-                for (int n = 0; n < KL; ++n) {
-                    const int t = tl + n * NT;
-                    const int k = t / (RW * N), t2 = t - k * RW * N, cc = t2 & (RW - 1), r = ((t2 >> 3) & 1) * (N / 2) + (t2 >> 4);
-                    L[(k * RW + cc) * LD + pos[r]] = v[n];
+                    for (int m = 0; m < 16; ++m) v[m] = line2[16 * m];
+#pragma unroll
+                    for (int m = 1; m < 16; ++m) v[m] = cmulc(v[m], twl[m * b2]);
+                    small_dft<16, false>(v);
+                    if (k2 == 2) {
+#pragma unroll
+                        for (int m = 0; m < 16; ++m) line2[16 * m] = v[m];
+                    }
                 }
-            }
-            __syncthreads();
-            TEAM_STAMP(8);
-            fft_lines_inv_t<NN, NN>(L, 3 * RW, LD, 1, twl);
-            TEAM_STAMP(9);
+                __syncthreads();
+                TEAM_STAMP(10);
+                if (tl < 2 * RW * 16) {
+                    const double2 *ql = L + (2 * RW + c2) * LD + b2;
+                    const double Uk = d.U[k2];
 #pragma unroll
-            for (int n = 0; n < 2 * RW * N / NT; ++n) {
-                const int t = tl + n * NT;
-                const int k = t / (RW * N), t2 = t - k * RW * N, r = t2 & (N - 1), cc = t2 >> 8;   // lanes along the line
-                const double2 uv = L[(k * RW + cc) * LD + r];
-                const double2 qq = L[(2 * RW + cc) * LD + r];
-                const double qv = k == 0 ? qq.x : qq.y;
-                L[(k * RW + cc) * LD + r] = make_double2((uv.x + d.U[k]) * qv, uv.y * qv);
-            }
-            __syncthreads();
-            TEAM_STAMP(10);
-            fft_lines_fwd_t<NN, NN>(L, 2 * RW, LD, 1, twl);
-            TEAM_STAMP(11);
+                    for (int m = 0; m < 16; ++m) {
+                        const double2 qq = ql[16 * m];
+                        const double qv = k2 == 0 ? qq.x : qq.y;
+                        v[m] = make_double2((v[m].x + Uk) * qv, v[m].y * qv);
+                    }
+                    small_dft<16, true>(v);
 #pragma unroll
-            for (int n = 0; n < 2 * RW * N / NT; ++n) {
-                const int t = tl + n * NT;
-                const int k = t / (RW * N), t2 = t - k * RW * N, cc = t2 & (RW - 1), r = ((t2 >> 3) & 1) * (N / 2) + (t2 >> 4);
-                X[(size_t)k * fz + (size_t)r * ZP + c0 + cc] = L[(k * RW + cc) * LD + pos[r]];
+                    for (int m = 1; m < 16; ++m) v[m] = cmul(v[m], twl[m * b2]);
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) line2[16 * m] = v[m];
+                }
+                __syncthreads();
+                TEAM_STAMP(11);
+                if (tl < 2 * RW * 16) {
+                    const double2 *base = L + (k1 * RW + cc) * LD + 16 * blk;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) v[m] = base[m];
+                    small_dft<16, true>(v);
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) X[(size_t)k1 * fz + (size_t)ipos[16 * blk + m] * ZP + c0 + cc] = v[m];
+                }
             }
             TEAM_STAMP(12);
             if (!team_barrier(ctr, ++phase * TEAM_WG, c, flags)) return;
@@ -1089,7 +1108,7 @@ static size_t team_lds(int N) {
     const int RW = N / TEAM_WG;
     const int NK = N / 2 + 1;
     return (size_t)3 * RW * (N + 1) * 16 + (size_t)N * 4 + (size_t)N * 16 + (size_t)RW * 4 * 16 + (size_t)RW * sizeof(TeamState) +
-           (size_t)TEAM_NTAB * (2 * TEAM_NT + RW) * 8 + (size_t)(NK + 1) * 8 + (size_t)RW * 8 + 64;
+           (size_t)TEAM_NTAB * (2 * TEAM_NT + RW) * 8 + (size_t)(NK + 1) * 8 + (size_t)RW * 8 + (size_t)N * 4 + 64;
 }
 
 // 1: the device runs 8 teams of 32 co-resident workgroups (census passed), 0: it does not.  Decided once per model.
