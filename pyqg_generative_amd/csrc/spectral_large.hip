@@ -965,24 +965,26 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
             if (s > 0) {
                 // ---- rows: forward along x of the two product fields, tendency, AB3 step ----
                 TEAM_STAMP(0);
-                {
-                    constexpr int KL = 2 * RW * N / NT;            // 8 loads per thread
-                    double2 v[KL];
+                // first radix-16 pass of the forward transform on operands taken straight from the exchange buffer: task
+                // (line, b) owns elements {b + 16 m} of its row, sixteen consecutive lanes read 256 contiguous bytes
+                if (tl < 2 * RW * 16) {
+                    const int b2 = tl & 15, line = tl >> 4;
+                    const int j = pair_row(p0 + (line >> 2), (line >> 1) & 1, N);
+                    const size_t ro = (size_t)(line & 1) * fz + (size_t)j * ZP + b2;
+                    double2 v[16];
 #pragma unroll
-                    for (int n = 0; n < KL; ++n) {
-                        const int t = tl + n * NT, e = t % N, line = t / N;
-                        const int j = pair_row(p0 + (line >> 2), (line >> 1) & 1, N);
-                        v[n] = team_ld(xrs, (size_t)(line & 1) * fz + (size_t)j * ZP + e);
-                    }
+                    for (int m = 0; m < 16; ++m) v[m] = team_ld(xrs, ro + 16 * m);
+                    small_dft<16, true>(v);
 #pragma unroll
-                    for (int n = 0; n < KL; ++n) {
-                        const int t = tl + n * NT;
-                        L[(t / N) * LD + t % N] = v[n];
-                    }
+                    for (int m = 1; m < 16; ++m) v[m] = cmul(v[m], twl[m * b2]);
+                    double2 *ln = L + line * LD + b2;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) ln[16 * m] = v[m];
                 }
                 __syncthreads();
                 TEAM_STAMP(1);
-                fft_lines_fwd_t<NN, NN>(L, 2 * RW, LD, 1, twl);
+                fft_pass<16, true>(L, 2 * RW, LD, 1, 16, N, twl);
+                __syncthreads();
                 TEAM_STAMP(2);
                 const int lev = a.ablevel0 + s - 1 > 2 ? 2 : a.ablevel0 + s - 1;
                 const double dt1 = a.c[lev][0], dt2 = a.c[lev][1], dt3 = a.c[lev][2];
@@ -1008,14 +1010,24 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
             if (nyq) build(nst[nr], HALF, nr, SL * NT + nr);
             __syncthreads();
             TEAM_STAMP(4);
-            fft_lines_inv_t<NN, NN>(L, 3 * RW, LD, 1, twl);
+            fft_pass<16, false>(L, 3 * RW, LD, 1, 16, N, twl);
+            __syncthreads();
             TEAM_STAMP(5);
-#pragma unroll
-            for (int n = 0; n < 3 * RW * N / NT; ++n) {
-                const int t = tl + n * NT, e = t % N, line = t / N;
+            // second radix-16 pass of the inverse in registers, rows stored straight to the exchange buffer
+            if (tl < 3 * RW * 16) {
+                const int b2 = tl & 15, line = tl >> 4;
                 const int rl = line / 3, f = line - rl * 3;
                 const int j = pair_row(p0 + (rl >> 1), rl & 1, N);
-                X[(size_t)f * fz + (size_t)j * ZP + e] = L[line * LD + e];
+                const double2 *ln = L + line * LD + b2;
+                double2 v[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) v[m] = ln[16 * m];
+#pragma unroll
+                for (int m = 1; m < 16; ++m) v[m] = cmulc(v[m], twl[m * b2]);
+                small_dft<16, false>(v);
+                double2 *xo = X + (size_t)f * fz + (size_t)j * ZP + b2;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) xo[16 * m] = v[m];
             }
             TEAM_STAMP(6);
             if (!team_barrier(ctr, ++phase * TEAM_WG, c, flags)) return;
