@@ -772,7 +772,9 @@ __device__ __forceinline__ double2 team_ld(__amdgpu_buffer_rsrc_t rs, size_t ele
 
 constexpr int TEAM_NT = 512, TEAM_WG = 32, TEAM_SPIN = 1 << 21;
 
-// every wave's stores reach L2, the workgroup arrives, lane 0 waits for the team.  false: timed out (flag raised)
+// every wave's stores reach L2, the workgroup arrives ONCE on the team's counter, thread 0 waits for the team.
+// (Measured alternatives: one arrival per wave = 1.9x the step time; per-workgroup epoch words in one 128-byte line
+// polled by a whole wave instead of the counter = +2 %.)  false: timed out (flag raised)
 __device__ __forceinline__ bool team_barrier(unsigned *ctr, unsigned target, TeamCtl *c, int *ok_lds) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -995,11 +997,12 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
                     tend(st, HALF, nr, SL * NT + nr, dt1, dt2, dt3);
                     nst[nr] = st;
                 }
-                __syncthreads();
                 TEAM_STAMP(3);
-                if (s == a.nsteps) break;
+                if (s == a.nsteps) { __syncthreads(); break; }
             }
             // ---- rows: build the three packed spectra from qh, inverse along x, publish the rows ----
+            // (the self-conjugate columns need q of their mirror row: published here, ONE barrier covers it and the
+            // tendency phase's last reads of the lines the build phase overwrites)
 #pragma unroll
             for (int e = 0; e < SL; ++e)
                 if (el_i[e] == 0) { qsc[(el_r[e] * 2) * 2] = S[e].q0; qsc[(el_r[e] * 2) * 2 + 1] = S[e].q1; }
