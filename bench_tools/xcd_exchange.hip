@@ -9,6 +9,12 @@
 // MODE 2: plain stores, vmcnt(0), arrive; NO fences; consumers load with sc1 (L1 bypass) -- relies on the team sharing
 //         one L2, which HW_REG_XCC_ID establishes
 // MODE 3: plain stores, vmcnt(0), arrive; acquire fence after the wait (L1 invalidate), plain loads
+// MODE 4: MODE 2 with TWO members in flight per team (two exchange buffers = 6.4 MB live per XCD, beyond its 4 MB L2):
+//         arrive for one member, work on the other, then wait — the barrier latency hides behind the other member's phase.
+//         Measured: 18.5 us per member against 12.2 us with one in flight — two live buffers overflow the L2 and cost more
+//         than the hidden barriers give.  (Timing probe only: its tag check is not reliable — the hand-written asm loads
+//         leave their destination registers unprotected until the s_waitcnt, which is why the product kernel issues its
+//         sc1 loads through the compiler's buffer-load builtin.)
 //   hipcc --offload-arch=gfx950 -O3 -o bench_tools/_build/xcd_exchange bench_tools/xcd_exchange.hip && bench_tools/_build/xcd_exchange
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -164,6 +170,146 @@ __global__ __launch_bounds__(NT) void k_exchange(double2 *X, const double2 *stre
     if (tid == 0 && rank == 0) { c->t_total[x][0] = (unsigned long long)(t1 - t0); c->t_total[x][1] = size; }
 }
 
+
+__device__ inline void arrive(unsigned *ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline bool wait_for(unsigned *ctr, unsigned target, Ctl *c) {
+    __shared__ int ok2;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        int good = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 21)) { atomicExch(&c->err, 1u); good = 0; break; }
+        }
+        ok2 = good;
+    }
+    __syncthreads();
+    return ok2 != 0;
+}
+
+__global__ __launch_bounds__(NT) void k_exchange2(double2 *X, Ctl *c, int members, int slots) {
+    extern __shared__ double2 lds[];
+    __shared__ unsigned s_x, s_rank, s_size;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        unsigned x = xcc_id() & 7u;
+        s_x = x;
+        s_rank = atomicAdd(&c->team_n[x][0], 1u);
+        __hip_atomic_fetch_add(&c->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&c->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 21)) { atomicExch(&c->err, 2u); break; }
+        }
+        s_size = __hip_atomic_load(&c->team_n[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const unsigned x = s_x, rank = s_rank, size = s_size;
+    if (c->err) return;
+    unsigned bad = 0;
+    unsigned ph[2] = {0, 0};
+    long long t0 = wall_clock64();
+    auto phaseA = [&](int sl, int m) {
+        double2 *Xt = X + ((size_t)sl * 8 + x) * 3 * FIELD;
+        for (int row = rank; row < N; row += size)
+            for (int i = tid; i < 3 * N; i += NT) {
+                int f = i >> 8, col = i & 255;
+                Xt[f * FIELD + (size_t)row * N + col] = tag(m, f, row, col, 0);
+            }
+    };
+    auto phaseB = [&](int sl, int m) {
+        double2 *Xt = X + ((size_t)sl * 8 + x) * 3 * FIELD;
+        for (int g = rank; g < N / 8; g += size) {
+            double2 v[6];
+            const double2 *p[6];
+            int rr[6], ff[6], cc[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                int i = tid + j * NT;
+                int col = g * 8 + (i & 7), row = (i >> 3) & 255, f = i >> 11;
+                rr[j] = row; ff[j] = f; cc[j] = col;
+                p[j] = &Xt[f * FIELD + (size_t)row * N + col];
+            }
+            load16_sc1<6>(v, p);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double2 e = tag(m, ff[j], rr[j], cc[j], 0);
+                bad += (v[j].x != e.x || v[j].y != e.y);
+                if (ff[j] < 2) *const_cast<double2 *>(p[j]) = tag(m, ff[j], rr[j], cc[j], 1);
+            }
+        }
+    };
+    auto phaseC = [&](int sl, int m) {
+        double2 *Xt = X + ((size_t)sl * 8 + x) * 3 * FIELD;
+        for (int r0 = rank; r0 < N; r0 += 4 * size) {
+            double2 v[4];
+            const double2 *p[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = r0 + j * size, f = tid >> 8, col = tid & 255;
+                p[j] = &Xt[(tid < 2 * N ? f : 0) * FIELD + (size_t)(row < N ? row : 0) * N + col];
+            }
+            load16_sc1<4>(v, p);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int row = r0 + j * size, f = tid >> 8, col = tid & 255;
+                if (tid < 2 * N && row < N) { double2 e = tag(m, f, row, col, 1); bad += (v[j].x != e.x || v[j].y != e.y); }
+            }
+        }
+    };
+    for (int it = 0; it < members; it += slots) {
+        const int m0 = it * 8 + x, m1 = (it + 1) * 8 + x;
+        unsigned *c0 = &c->bar[x][0], *c1 = &c->bar[x][16];
+        if (slots == 2) {
+            phaseA(0, m0); arrive(c0); ++ph[0];
+            phaseA(1, m1); arrive(c1); ++ph[1];
+            if (!wait_for(c0, ph[0] * size, c)) return;
+            phaseB(0, m0); arrive(c0); ++ph[0];
+            if (!wait_for(c1, ph[1] * size, c)) return;
+            phaseB(1, m1); arrive(c1); ++ph[1];
+            if (!wait_for(c0, ph[0] * size, c)) return;
+            phaseC(0, m0); arrive(c0); ++ph[0];
+            if (!wait_for(c1, ph[1] * size, c)) return;
+            phaseC(1, m1); arrive(c1); ++ph[1];
+            if (!wait_for(c0, ph[0] * size, c)) return;
+            if (!wait_for(c1, ph[1] * size, c)) return;
+        } else {
+            phaseA(0, m0); arrive(c0); ++ph[0];
+            if (!wait_for(c0, ph[0] * size, c)) return;
+            phaseB(0, m0); arrive(c0); ++ph[0];
+            if (!wait_for(c0, ph[0] * size, c)) return;
+            phaseC(0, m0); arrive(c0); ++ph[0];
+            if (!wait_for(c0, ph[0] * size, c)) return;
+        }
+    }
+    long long t1 = wall_clock64();
+    if (bad) atomicAdd(&c->bad, bad);
+    if (tid == 0 && rank == 0) { c->t_total[x][0] = (unsigned long long)(t1 - t0); c->t_total[x][1] = size; }
+}
+
+static void run2(int members, int slots, double2 *X, Ctl *c, int ncu) {
+    CK(hipMemset(c, 0, sizeof(Ctl)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    size_t lds = 96 * 1024;
+    CK(hipFuncSetAttribute((const void *)k_exchange2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_exchange2, dim3(ncu), dim3(NT), lds, 0, X, c, members, slots);
+    CK(hipEventRecord(e1));
+    CK(hipDeviceSynchronize());
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    Ctl h;
+    CK(hipMemcpy(&h, c, sizeof(Ctl), hipMemcpyDeviceToHost));
+    printf("mode 4 members/xcd %3d, %d in flight: %8.1f us total, %6.2f us per member per XCD  err %u bad %u\n", members, slots,
+           ms * 1e3, ms * 1e3 / members, h.err, h.bad);
+    fflush(stdout);
+}
+
 template <int MODE>
 static void run(int members, int stream_lines, double2 *X, double2 *sin, double2 *sout, Ctl *c, int ncu) {
     CK(hipMemset(c, 0, sizeof(Ctl)));
@@ -194,15 +340,16 @@ int main(int argc, char **argv) {
     printf("%s, %d CUs\n", prop.name, ncu);
     double2 *X, *sin, *sout;
     Ctl *c;
-    CK(hipMalloc(&X, 8 * 3 * FIELD * sizeof(double2)));
+    CK(hipMalloc(&X, 16 * 3 * FIELD * sizeof(double2)));
     const int max_lines = 40;                          // lines of 256 double2 per workgroup and member
     size_t stream = (size_t)members * 8 * 40 * max_lines * 256;
     CK(hipMalloc(&sin, stream * sizeof(double2)));
     CK(hipMalloc(&sout, stream * sizeof(double2)));
     CK(hipMemset(sin, 0, stream * sizeof(double2)));
     CK(hipMalloc(&c, sizeof(Ctl)));
-    for (int rep = 0; rep < 2; ++rep) {
-        for (int sl : {0, 25}) {
+    for (int rep = 0; rep < 3; ++rep) { run2(members, 1, X, c, ncu); run2(members, 2, X, c, ncu); }
+    for (int rep = 0; rep < 1; ++rep) {
+        for (int sl : {0}) {
             run<0>(members, sl, X, sin, sout, c, ncu);
             run<1>(members, sl, X, sin, sout, c, ncu);
             run<2>(members, sl, X, sin, sout, c, ncu);
