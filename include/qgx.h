@@ -124,7 +124,12 @@ typedef struct qgx_param {
 } qgx_param;
 
 /* advance `nsteps_to_run` steps; `p` may be NULL (unparameterized, simulate.py:121).
- * If `refresh_diag` != 0 the last step also stores ph,u,v (as pyqg keeps them). */
+ * If `refresh_diag` != 0 the last step also stores ph,u,v (as pyqg keeps them).
+ * 256 x 256 grids, p == NULL: the steps of a call that neither refresh ph,u,v nor have a diagnostics increment due
+ * are executed by ONE persistent launch that occupies every CU of the device (state in registers, row/column exchange
+ * in the XCDs' L2); a flag raised inside it (a bounded wait timed out because other work held CUs for seconds) is
+ * reported as QGX_ERR_HIP by the NEXT call that touches the model, whose state is then undefined.  Issue such calls
+ * on one stream at a time. */
 int qgx_step(qgx_model *m, int nsteps_to_run, const qgx_param *p, int refresh_diag, void *stream);
 /* step counter / ablevel (m.tc) and reset of the AB history */
 int64_t qgx_step_count(const qgx_model *m);
