@@ -859,6 +859,20 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
     }
     int cur = 0;
     QGX_STAMP()
+    // The epilogue of one (tile, half) unit — bias / ReLU / hi-lo split on the VALU and 16 output stores per lane — is
+    // issued INSIDE the MFMA loop of the next unit, a tile of it after each K step: done back to back, all eight waves
+    // of the CU converted and stored at the same time and then all multiplied at the same time, so the matrix pipe, the
+    // VALU and the memory pipe (10 B/clk of HBM write rate per CU: 26 k cycles per tile, the kernel's floor) took
+    // turns instead of overlapping.  Two accumulator sets (one per half) ping-pong.
+    f32x16 acc[2][MT][2];
+    char *ob_prev = nullptr;
+    auto epilogue_tile = [&](const f32x16 (&ac)[MT][2], int e, char *obase, int half_of) {
+        const int mt = e >> 1, nt = e & 1;
+        const int tile = wave + NW * mt;
+        if (tile >= ntiles) return;
+        char *pix = obase + (size_t)(tile * 32 + li) * (COUT * 4);
+        store_tile_t<2, false>(ac[mt][nt], half_of * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
+    };
     for (int ti = 0; ti < n_my; ++ti) {
         const bool have_next = ti + 1 < n_my;
         f32x4 pv[PPT];
@@ -868,15 +882,17 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
         const int b = tile_g / tiles_per_img;
         const int y0 = (tile_g - b * tiles_per_img) * R;
         char *ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N * N + (size_t)y0 * N) * (COUT * 4);
-#pragma unroll 1
+#pragma unroll
         for (int half = 0; half < 2; ++half) {
-            f32x16 acc[MT][2];
+            // the unit whose results are converted and stored under this unit's MFMAs
+            const bool have_prev = half == 1 || ti > 0;
+            char *const obp = half == 1 ? ob : ob_prev;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc[half][mt][nt][r] = 0.f;
             const char *wl = wl0 + (h * COUT + half * 64 + li) * 16;
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
@@ -914,30 +930,30 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], Ph[mt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Pl[mt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Ph[mt], acc[mt][nt], 0, 0, 0);
+                        acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], Ph[mt], acc[half][mt][nt], 0, 0, 0);
+                        acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Pl[mt], acc[half][mt][nt], 0, 0, 0);
+                        acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Ph[mt], acc[half][mt][nt], 0, 0, 0);
                     }
+                if (have_prev) {
+#pragma unroll
+                    for (int e = 0; e < 2 * MT; ++e)
+                        if ((e * NSTEP) / (2 * MT) == s) epilogue_tile(acc[half ^ 1], e, obp, half ^ 1);
+                }
             }
             QGX_STAMP()
-            // the next patch goes to LDS before this tile's first output store is issued: waiting for its
-            // loads later would also wait for those stores (one in-order counter)
+            // the next patch goes to LDS once its loads have landed.  (gfx9 counts loads and stores in one counter and the
+            // compiler must assume they retire out of order, so this wait also drains the stores issued above; moving the
+            // prefetch so that no store is in flight at the wait measured the same time: the drain is not what bounds it.)
             if (half == 0 && have_next) QGX_F_STORE(pl0 + (cur ^ 1) * patch_bytes, pv)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int tile = wave + NW * mt;
-                if (tile >= ntiles) continue;
-                char *pix = ob + (size_t)(tile * 32 + li) * (COUT * 4);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    store_tile_t<2, false>(acc[mt][nt], half * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
-            }
-            QGX_STAMP()
         }
+        ob_prev = ob;
         __syncthreads();
         QGX_STAMP()
         cur ^= 1;
     }
+    // the last unit's results
+#pragma unroll
+    for (int e = 0; e < 2 * MT; ++e) epilogue_tile(acc[1], e, ob_prev, 1);
 #undef QGX_F_LOAD
 #undef QGX_F_STORE
 }
