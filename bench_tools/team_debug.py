@@ -1,3 +1,5 @@
+"""Developer tool: largest difference between the XCD-resident run kernel and the three-launch step after N
+unparameterized 256 x 256 steps from the same state (where, and how many elements).   python bench_tools/team_debug.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
