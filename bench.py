@@ -242,10 +242,11 @@ def leg_config4(qa, device, K, W):
     eng.step(W)
     pp = dict(qa.engine.PYQG_DEFAULTS)
 
-    def coarsegrain():
+    def coarsegrain():                              # as generate_subgrid_forcing does at a snapshot
         q = eng.get(_lib.F_Q)
+        qh, adv_hat = Dev.hires_tendency_hat(q, pp, '3/2-rule')
         for op in (Dev.Operator2, Dev.Operator5):
-            Dev.PV_subgrid_forcing(q, nc, op, pp, '3/2-rule')
+            Dev.subgrid_forcing_from_hat(qh, adv_hat, nc, op, pp, '3/2-rule')
     coarsegrain()                                   # plan creation outside the timed region
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]   # qgx_step launches on torch's current stream
 

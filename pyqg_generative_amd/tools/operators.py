@@ -228,9 +228,103 @@ class Dev:
         u, v = e.get(_lib.F_U), e.get(_lib.F_V)
         return (u, v, e) if return_engine else (u, v)
 
+    # ---- the same diagnostic kept in spectral space ------------------------------------------------
+    # The reference composes PV_subgrid_forcing from numpy-level operators, each of which transforms to and from grid
+    # space: per high-resolution field and operator 14 transforms of the 256 / 384 grids, 9 of them round trips that
+    # cancel.  Below the high-resolution tendency is computed ONCE per snapshot for all operators and stays spectral
+    # between the steps: 5 large transforms per field (3/2-rule) + the inversion.  Same operations in exact arithmetic;
+    # the results agree with the composed form to rounding (tests/test_gpu_operators.py).
+    _HAT_OPERATORS = ('Operator1', 'Operator2', 'Operator4', 'Operator5', 'cut_off')
+
     @classmethod
-    def PV_subgrid_forcing(cls, q, nc, operator, pyqg_params, dealias='none', return_psi=False):
-        """q: (B,2,N,N) device tensor.  -> (forcing, qf, uf, vf [, psi_f]) on the nc grid, each (B,2,nc,nc)."""
+    def _operator_hat(cls, operator, Xh, nc):
+        """operator applied to the spectrum Xh (M,N,N/2+1) -> spectrum on the nc grid, or None (no spectral form)"""
+        N = Xh.shape[-2]
+        dev = Xh.device.index or 0
+        sc = 1.0 / (N / nc) ** 2
+        name = getattr(operator, '__name__', '')
+        if name == 'Operator1':
+            return cls.regrid(Xh, nc, scale=sc, zero_dst_2h=True, filt=cls.table(nc, 'filtr', dev))
+        if name == 'Operator2':
+            return cls.regrid(Xh, nc, scale=sc, zero_dst_2h=True, filt=cls.table(nc, ('gauss', 2.0), dev))
+        if name == 'Operator4':
+            y = cls.regrid(Xh, nc, scale=sc, zero_dst_2h=True, filt=cls.table(nc, ('gauss', 2.0), dev))
+            return cls.regrid(y, nc, filt=cls.table(nc, 'filtr', dev))
+        if name in ('Operator5', 'cut_off'):
+            if nc % 2:
+                raise ValueError('nc must be even')
+            return cls.regrid(Xh, nc, scale=sc, zero_dst_2h=FILTER_2h_HARMONICS)
+        return None
+
+    @classmethod
+    def advect_hat(cls, qh, uh, vh, dealias='none'):
+        """spectrum of div(u q, v q) from the spectra of q, u, v (each (M,n,n/2+1)); the arithmetic of advect()"""
+        n = qh.shape[-2]
+        if dealias == 'none':
+            a, b, c = (cls.irfft2(t) for t in (qh, uh, vh))
+            return cls.spec_div(cls.rfft2(cls.mul(a, b)), cls.rfft2(cls.mul(a, c)))
+        if dealias == '3/2-rule':
+            N = int((n * 3) // 2)
+            up = lambda t: cls.irfft2(cls.regrid(t, N, scale=(N / n) ** 2, zero_src_2h=True, zero_dst_2h=True))
+            down = lambda t: cls.regrid(cls.rfft2(t), n, scale=(n / N) ** 2, zero_src_2h=True, zero_dst_2h=True)
+            a, b, c = up(qh), up(uh), up(vh)
+            return cls.spec_div(down(cls.mul(a, b)), down(cls.mul(a, c)))
+        if dealias == '2/3-rule':
+            sharp = cls.table(n, 'sharp', qh.device.index or 0)
+            a, b, c = (cls.irfft2(cls.regrid(t, n, filt=sharp)) for t in (qh, uh, vh))
+            return cls.regrid(cls.spec_div(cls.rfft2(cls.mul(a, b)), cls.rfft2(cls.mul(a, c))), n, filt=sharp)
+        raise ValueError('dealias should be none or 2/3-rule or 3/2-rule')
+
+    @classmethod
+    def hires_tendency_hat(cls, q, pyqg_params, dealias='none'):
+        """(spectrum of q, spectrum of its advective tendency div(u q, v q)) of PV fields q (B,2,N,N): the part of the
+        subgrid-forcing diagnostic that depends neither on the operator nor on the coarse resolution"""
+        B, _, N, _ = q.shape
+        e = cls.inversion_model(N, B, q.device.index or 0, pyqg_params)
+        e.set_q(q)
+        e.invert()
+        flat = lambda t: t.reshape(-1, t.shape[-2], t.shape[-1])
+        qh, ph = flat(e.get(_lib.F_QH)), flat(e.get(_lib.F_PH))
+        vh = cls.spec_div(ph, None)                               # i k psi
+        uh = cls.regrid(cls.spec_div(None, ph), N, scale=-1.0)    # -i l psi
+        return qh, cls.advect_hat(qh, uh, vh, dealias)
+
+    @classmethod
+    def subgrid_forcing_from_hat(cls, qh, adv_hat, nc, operator, pyqg_params, dealias='none', return_psi=False):
+        """the operator- and resolution-dependent rest: coarse PV, its velocities and tendency, the filtered
+        high-resolution tendency.  qh, adv_hat: (2B,N,N/2+1) from hires_tendency_hat"""
+        B = qh.shape[0] // 2
+        flat = lambda t: t.reshape(-1, t.shape[-2], t.shape[-1])
+        qf = cls.irfft2(cls._operator_hat(operator, qh, nc)).reshape(B, 2, nc, nc)
+        uf, vf, coarse = cls.velocities(qf, pyqg_params, return_engine=True)
+        psi = coarse.get(_lib.F_P) if return_psi else None        # before the engine is reused / evicted
+        adv_c = cls.advect(flat(qf), flat(uf), flat(vf), dealias)
+        adv_f = cls.irfft2(cls._operator_hat(operator, adv_hat, nc))
+        forcing = cls.mul(adv_c, None, 1.0, adv_f, -1.0).reshape(B, 2, nc, nc)
+        return (forcing, qf, uf, vf, psi) if return_psi else (forcing, qf, uf, vf)
+
+    @classmethod
+    def has_spectral_form(cls, operator):
+        return getattr(operator, '__name__', '') in cls._HAT_OPERATORS
+
+    @classmethod
+    def PV_subgrid_forcing_multi(cls, q, nc, operators, pyqg_params, dealias='none', return_psi=False):
+        """PV_subgrid_forcing for several operators at once: the inversion and the advection of the high-resolution
+        fields are shared.  -> list of (forcing, qf, uf, vf [, psi_f]) in the order of `operators`, or None when one
+        of them has no spectral form (callers then use the composed PV_subgrid_forcing)."""
+        if not all(cls.has_spectral_form(op) for op in operators):
+            return None
+        qh, adv_hat = cls.hires_tendency_hat(q, pyqg_params, dealias)
+        return [cls.subgrid_forcing_from_hat(qh, adv_hat, nc, op, pyqg_params, dealias, return_psi) for op in operators]
+
+    @classmethod
+    def PV_subgrid_forcing(cls, q, nc, operator, pyqg_params, dealias='none', return_psi=False, composed=False):
+        """q: (B,2,N,N) device tensor.  -> (forcing, qf, uf, vf [, psi_f]) on the nc grid, each (B,2,nc,nc).
+        composed=True: the reference's sequence of grid-space operators (operators.py:283-287) step by step."""
+        if not composed:
+            fast = cls.PV_subgrid_forcing_multi(q, nc, [operator], pyqg_params, dealias, return_psi)
+            if fast is not None:
+                return fast[0]
         B, _, N, _ = q.shape
         flat = lambda t: t.reshape(-1, t.shape[-2], t.shape[-1])
         u, v = cls.velocities(q, pyqg_params)

@@ -137,11 +137,18 @@ def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n
     out = {}
     for _ in m.run_with_snapshots(tsnapint=sampling_freq):
         qd = m.q_device()
+        # the high-resolution inversion + advection does not depend on the operator or on nc: once per snapshot
+        hat = Dev.hires_tendency_hat(qd, coarse_params, dealias) \
+            if all(Dev.has_spectral_form(getattr(Dev, o)) for o in operators) else None
         for opname in operators:
             dev_op = getattr(Dev, opname)
             for nc in Nc:
-                forcing, qf, uf, vf, psi = Dev.PV_subgrid_forcing(qd, nc, dev_op, coarse_params, dealias,
-                                                                  return_psi=True)
+                if hat is not None:
+                    forcing, qf, uf, vf, psi = Dev.subgrid_forcing_from_hat(hat[0], hat[1], nc, dev_op, coarse_params,
+                                                                            dealias, return_psi=True)
+                else:
+                    forcing, qf, uf, vf, psi = Dev.PV_subgrid_forcing(qd, nc, dev_op, coarse_params, dealias,
+                                                                      return_psi=True)
                 data = {'q_forcing_advection': (dims, pack(forcing)), 'q': (dims, pack(qf)),
                         'u': (dims, pack(uf)), 'v': (dims, pack(vf)), 'psi': (dims, pack(psi))}
                 xc = ((np.arange(nc) + 0.5) / nc * m.L).astype('float32')
