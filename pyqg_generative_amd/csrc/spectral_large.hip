@@ -132,9 +132,9 @@ __global__ void k_l_unpack_real(SpecDev d, const double2 *zbuf, double *r) {
 }
 
 // dst[b][0], dst[b][1] <- half spectra of the two real fields packed in zbuf[b][0] (after fwd FFT)
-__global__ void k_l_unpack_pair(SpecDev d, const double2 *zbuf, double2 *dst, int zero_mean) {
+__global__ void k_l_unpack_pair(SpecDev d, const double2 *zbuf, double2 *dst, int zero_mean, int field) {
     const int N = d.N, NK = d.NK, sz = N * NK, b = blockIdx.y;
-    const double2 *Z = zbuf + (size_t)b * ZF * N * N;
+    const double2 *Z = zbuf + ((size_t)b * ZF + field) * N * N;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < sz; idx += gridDim.x * blockDim.x) {
         const int j = idx / NK, i = idx - j * NK;
         const double2 a = Z[(size_t)j * N + i];
@@ -568,18 +568,45 @@ static int fft2d_large(const SpecDev &d, double2 *base, int k0, int nfpm, hipStr
 
 static dim3 pw_grid(const SpecDev &d, int n) { return dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256), d.B); }
 
+// rfft2 / irfft2 of (B,2,N,N) fields.  Fused form: the real -> complex packing rides in the row kernel's staging and the
+// complex -> real split in the column kernel's store (3 / 2 launches and no separate pack / unpack sweep of the work field
+// instead of 4 launches); the unfused form remains for tile shapes the fused kernels do not cover.
+static bool fused_transforms_ok(int N, int lpb) { return lpb >= 2 && lpb % 2 == 0 && (N / 2) % (lpb / 2) == 0 && N % lpb == 0; }
+
 int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st) {
     const SpecDev &d = m->d;
+    const int lpb = lines_per_block(d.N);
+    static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+    if (!unfused && fused_transforms_ok(d.N, lpb)) {
+        const size_t lds = lines_lds(d.N, lpb);
+        hipLaunchKernelGGL(k_l_rows_S, dim3(d.B * (d.N / lpb)), dim3(256), lds, st, d, q, m->zbuf, 1.0, lpb);
+        hipLaunchKernelGGL(k_l_cols<1>, dim3(d.B * (d.N / lpb)), dim3(256), lds, st, d, m->zbuf, (double *)nullptr,
+                           (double *)nullptr, (double *)nullptr, lpb);
+        hipLaunchKernelGGL(k_l_unpack_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->zbuf, qh, 0, 2);
+        QGX_HIP(hipGetLastError());
+        return QGX_OK;
+    }
     hipLaunchKernelGGL(k_l_pack_real, pw_grid(d, d.N * d.N), dim3(256), 0, st, d, q, m->zbuf, 1.0);
     int rc = fft2d_large<true>(d, m->zbuf, 0, 1, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_l_unpack_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->zbuf, qh, 0);
+    hipLaunchKernelGGL(k_l_unpack_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->zbuf, qh, 0, 0);
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
 
 int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st) {
     const SpecDev &d = m->d;
+    const int lpb = lines_per_block(d.N);
+    static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+    if (!unfused && fused_transforms_ok(d.N, lpb)) {
+        const size_t lds = lines_lds(d.N, lpb);
+        hipLaunchKernelGGL(k_l_rows_build_inv<1>, dim3(d.B * ((d.N / 2) / (lpb / 2))), dim3(256), lds, st, d, qh, m->zbuf,
+                           (double2 *)nullptr, lpb / 2, d.N);
+        hipLaunchKernelGGL(k_l_cols<2>, dim3(d.B * (d.N / lpb)), dim3(256), lds, st, d, m->zbuf, q, (double *)nullptr,
+                           (double *)nullptr, lpb);
+        QGX_HIP(hipGetLastError());
+        return QGX_OK;
+    }
     hipLaunchKernelGGL(k_l_build_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, qh, m->zbuf);
     int rc = fft2d_large<false>(d, m->zbuf, 0, 1, st);
     if (rc) return rc;
@@ -605,7 +632,7 @@ static int large_step_unfused(qgx_model *m, const StepArgs &a, hipStream_t st) {
     if (a.has_S) {
         hipLaunchKernelGGL(k_l_pack_real, pw_grid(d, d.N * d.N), dim3(256), 0, st, d, a.S, m->zbuf, a.weight);
         if ((rc = fft2d_large<true>(d, m->zbuf, 0, 1, st))) return rc;
-        hipLaunchKernelGGL(k_l_unpack_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->zbuf, a.dqh, a.demean);
+        hipLaunchKernelGGL(k_l_unpack_pair, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->zbuf, a.dqh, a.demean, 0);
     }
     hipLaunchKernelGGL(k_l_build_uv, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, a.qh_in, m->zbuf,
                        a.diag ? a.ph : (double2 *)nullptr);
