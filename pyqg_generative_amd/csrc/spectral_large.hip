@@ -783,7 +783,6 @@ struct TeamArgs {
     double c[3][3];              // (dt1, dt2, dt3) of AB level 0, 1, 2
 };
 
-typedef double v2d_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned team_xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u; }
 
