@@ -135,3 +135,27 @@ def test_state_changes_between_runs_are_honoured():
     assert e1.tc == e2.tc == 11
     e1.close()
     e2.close()
+
+
+@pytest.mark.parametrize('params', [dict(dt=3600., rek=7e-8, delta=0.1, beta=1e-11), dict(dt=1800., rek=0.0),
+                                    dict(dt=3600., U1=0.05, U2=0.01, rd=20000.)])
+def test_runs_with_other_physical_parameters(params):
+    """jet parameters, no bottom friction, other shear / deformation radius: tables and constants reach the run kernel"""
+    import pyqg_generative_amd._lib as L
+    B = 8
+    q0 = _eddy_like_q(np.random.RandomState(81), B, 256)
+    e1, e2 = _engine(B, **params), _engine(B, **params)
+    e1.set_q(q0)
+    e2.set_q(q0)
+    e1.step(9, refresh_diag=False)
+    with _no_team():
+        e2.step(9, refresh_diag=False)
+    for f in (L.F_QH, L.F_DQHDT, L.F_DQHDT_PP):
+        assert _rel(e1.get(f).cpu().numpy(), e2.get(f).cpu().numpy()) < 1e-13
+    m = qg_ref.QGModelRef(nx=256, **params)
+    m.set_q(q0[0])
+    for _ in range(9):
+        m._step_forward()
+    assert _rel(e1.get(L.F_QH).cpu().numpy()[0], m.qh) < F64_TOL * 9
+    e1.close()
+    e2.close()
