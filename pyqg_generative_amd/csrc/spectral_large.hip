@@ -780,6 +780,7 @@ struct TeamArgs {
     double2 *X;                  // team x works in zbuf slot x: ZF fields of N rows at pitch ZP
     TeamCtl *ctl;
     int nsteps, ablevel0, ZP, census_only;
+    int fault;                   // test hook (QGX_TEAM_FAULT): finish the run, then raise the time-out flag
     double c[3][3];              // (dt1, dt2, dt3) of AB level 0, 1, 2
 };
 
@@ -1143,6 +1144,7 @@ __global__ __launch_bounds__(TEAM_NT) void k_l_team_steps(SpecDev d, TeamArgs a)
         }
         __syncthreads();
     }
+    if (a.fault && tid == 0 && blockIdx.x == 0) atomicExch(&c->err, 1u);
 }
 
 static size_t team_lds(int N) {
@@ -1210,6 +1212,7 @@ int large_team_steps(qgx_model *m, int K, int ablevel0, const double coef[3][3],
     a.qh_src = qh_src; a.qh_dst = qh_dst; a.p_src = p_src; a.pp_src = pp_src; a.p_dst = p_dst; a.pp_dst = pp_dst;
     a.X = m->zbuf; a.ctl = (TeamCtl *)m->team_ctl;
     a.nsteps = K; a.ablevel0 = ablevel0; a.ZP = m->N + large_zpad(); a.census_only = 0;
+    a.fault = getenv("QGX_TEAM_FAULT") != nullptr;       // test hook: the flag path of large_team_check
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a.c[i][j] = coef[i][j];
     QGX_HIP(hipMemsetAsync(m->team_ctl, 0, sizeof(TeamCtl), st));
     hipLaunchKernelGGL((k_l_team_steps<256>), dim3(8 * TEAM_WG), dim3(TEAM_NT), team_lds(256), st, m->d, a);

@@ -159,3 +159,21 @@ def test_runs_with_other_physical_parameters(params):
     assert _rel(e1.get(L.F_QH).cpu().numpy()[0], m.qh) < F64_TOL * 9
     e1.close()
     e2.close()
+
+
+def test_a_flag_raised_by_the_run_kernel_surfaces_at_the_next_call():
+    """the kernel's bounded waits raise a flag instead of hanging; the next C-ABI call that touches the model reports
+    it (here raised by a test hook at the end of an otherwise complete run) and the path is switched off"""
+    import pyqg_generative_amd._lib as L
+    e = _engine(8, dt=3600.)
+    e.set_q(_eddy_like_q(np.random.RandomState(82), 8, 256))
+    os.environ['QGX_TEAM_FAULT'] = '1'
+    try:
+        e.step(5, refresh_diag=False)              # launches asynchronously: no error yet
+        with pytest.raises(RuntimeError, match='XCD-resident step kernel raised flag'):
+            e.get(L.F_QH)
+    finally:
+        del os.environ['QGX_TEAM_FAULT']
+    e.step(4, refresh_diag=False)                  # the three-launch path from here on
+    assert e.tc == 9 and np.isfinite(e.get(L.F_QH).cpu().numpy()).all()
+    e.close()
