@@ -47,6 +47,23 @@ struct SpecDev {
     double H[2], Htot;
 };
 
+// Work the spectral step kernel does on the generator's behalf (small grids in layer-split form, GAN / VAE):
+//  * y != null: the forcing is still the net's raw output (B,2,N,N) float; the kernel's prologue does what k_finish<false>
+//    does — S = double(y * y_std) - mean_{y,x} — with the same arithmetic and summation order, and stores S;
+//  * X != null: the kernel's epilogue assembles the NEXT step's network input from q^{n+1} and fresh white noise,
+//    X = [float(q)/x_std, z], z = b * xi(Philox; seed, member, step) — what k_prep_noise does with a == 0.
+struct GenFuse {
+    const float *y = nullptr;
+    float ys[2] = {1.f, 1.f};
+    int demean = 0;
+    unsigned *range = nullptr;      // the generator's range-guard words (conv.hip)
+    float *X = nullptr;
+    float *z = nullptr;
+    float xs[2] = {1.f, 1.f};
+    float b = 1.f;
+    uint64_t seed = 0, member_offset = 0, step = 0;
+};
+
 // Arguments of one time step (spectral_small.hip / spectral_large.hip).
 struct StepArgs {
     const double2 *qh_in;   // (B,2,N,NK)
@@ -61,6 +78,7 @@ struct StepArgs {
     double dt1, dt2, dt3;
     double weight;
     int has_S, demean, diag;
+    GenFuse gf;
 };
 
 }  // namespace qgx
@@ -95,6 +113,8 @@ struct qgx_model {
     bool have_noise = false;
     int64_t const_counter = 0;
     bool have_forcing = false;
+    const void *x_ready_gen = nullptr;     // the generator whose input the last step kernel assembled (GenFuse::X), or null
+    uint64_t x_ready_step = 0;             //   ... for this noise step
     int64_t tc = 0;
     int ablevel = 0;
     uint64_t noise_step = 0;
@@ -114,8 +134,13 @@ struct NoiseUpdate {
     uint64_t seed, member_offset, step;
     double a, b;
 };
+// defer != null (GAN / VAE): the output kernel is skipped and *defer describes what the step kernel has to do instead
+// (GenFuse::y ...); input_ready: the previous step kernel already assembled the network input (GenFuse::X ...)
 int generator_forward(qgx_generator *g, const double *q, const void *z, double *S, int B, int N,
-                      int demean, hipStream_t st, const NoiseUpdate *nu);
+                      int demean, hipStream_t st, const NoiseUpdate *nu, GenFuse *defer = nullptr, bool input_ready = false);
+// the generator's input buffer, input scales and range words for the GenFuse::X part (after reserve)
+int generator_input_info(qgx_generator *g, int B, int N, GenFuse *gf);
+bool small_layer_split(const SpecDev &d);
 bool generator_noise_is_double(const qgx_generator *g);
 int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st);
 int noise_update(void *z, const void *xi_ext, bool is_double, int B, int n_per_member, uint64_t seed,

@@ -1952,8 +1952,16 @@ static int calibrate(qgx_generator *g) {
 
 bool generator_noise_is_double(const qgx_generator *g) { return g->kind == QGX_GEN_GZ; }
 
+int generator_input_info(qgx_generator *g, int B, int N, GenFuse *gf) {
+    QGX_REQUIRE(g && gf && g->kind != QGX_GEN_GZ, "generator_input_info: bad argument");
+    int rc = reserve(g, B, N);
+    if (rc) return rc;
+    gf->X = g->X; gf->xs[0] = g->x_std[0]; gf->xs[1] = g->x_std[1]; gf->range = g->range_dev;
+    return QGX_OK;
+}
+
 int generator_forward(qgx_generator *g, const double *q, const void *z, double *S, int B, int N,
-                      int demean, hipStream_t st, const NoiseUpdate *nu) {
+                      int demean, hipStream_t st, const NoiseUpdate *nu, GenFuse *defer, bool input_ready) {
     QGX_REQUIRE(g && q && z && S && B > 0, "generator_forward: bad argument");
     int rc = reserve(g, B, N);
     if (rc) return rc;
@@ -1969,7 +1977,9 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
         hipLaunchKernelGGL(k_finish<true>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)g->Y1,
                            (const double *)z, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
     } else {
-        if (nu) {
+        if (input_ready) {
+            // the previous step kernel wrote X and z (GenFuse::X)
+        } else if (nu) {
             dim3 qg((2 * npix / 4 + 255) / 256, B);
             hipLaunchKernelGGL(k_prep_noise, qg, pb, 0, st, q, (float *)const_cast<void *>(z), (const float *)nu->xi_ext,
                                g->X, npix, g->x_std[0], g->x_std[1], nu->seed, nu->member_offset, nu->step,
@@ -1978,8 +1988,13 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
             hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)z, g->X, 4, npix, g->x_std[0], g->x_std[1], g->range_dev);
         }
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
-        hipLaunchKernelGGL(k_finish<false>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)nullptr,
-                           (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
+        if (defer) {
+            defer->y = g->Y0; defer->ys[0] = g->y_std[0]; defer->ys[1] = g->y_std[1]; defer->demean = demean;
+            defer->range = g->range_dev;
+        } else {
+            hipLaunchKernelGGL(k_finish<false>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)nullptr,
+                               (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
+        }
     }
     QGX_HIP(hipGetLastError());
     return QGX_OK;

@@ -40,8 +40,9 @@ int large_team_steps(qgx_model *m, int K, int ablevel0, const double coef[3][3],
 
 // One _step_forward: AB3 coefficient schedule of kernel.pyx::_forward_timestep, history rotation.
 static int model_step_once(qgx_model *m, bool has_S, const double *S, double weight, int demean, int diag,
-                           hipStream_t st) {
+                           hipStream_t st, const GenFuse *gf = nullptr) {
     StepArgs a;
+    if (gf) a.gf = *gf;
     const double dt = m->cfg.dt;
     if (m->ablevel == 0) { a.dt1 = dt; a.dt2 = 0.0; a.dt3 = 0.0; m->ablevel = 1; }
     else if (m->ablevel == 1) { a.dt1 = 1.5 * dt; a.dt2 = -0.5 * dt; a.dt3 = 0.0; m->ablevel = 2; }
@@ -398,6 +399,8 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
     }
     if (!m->small) { int trc = large_team_check(m, st); if (trc) return trc; }
     const bool plain = !(p && (p->gen || p->forcing_dev));
+    const bool fuse_ok = getenv("QGX_NO_GENFUSE") == nullptr;            // A/B aid (tests toggle it)
+    m->x_ready_gen = nullptr;                                            // an assembled input never outlives its call
     for (int s = 0; s < nsteps; ++s) {
         if (plain && !m->small && large_team_available(m, st)) {
             // a run of steps with no diagnostics increment due inside it and no (u, v, psi) refresh asked of it
@@ -422,6 +425,8 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         const double *S = nullptr;
         double weight = 1.0;
         int demean_in_kernel = 0;
+        GenFuse gf;
+        bool use_gf = false;
         if (p && p->gen) {
             weight = p->weight;
             bool compute = true;
@@ -449,10 +454,27 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
             }
             if (compute) {
                 if (!m->small) { int qrc = large_ensure_q(m, st); if (qrc) return qrc; }
+                // Small grids in layer-split form, GAN / VAE: the generator's output kernel rides in the step kernel's
+                // prologue (unless this step's diagnostics need S first) and — white-in-time Philox noise, more steps to
+                // come in this call — the next step's input kernel in its epilogue (GenFuse, common.hpp)
+                const bool fusable = fuse_ok && m->small && small_layer_split(m->d) && !m->z_double;
+                const bool diag_due = m->dg_every > 0 && m->tc >= 1 && m->tc >= m->dg_start && m->tc % m->dg_every == 0;
+                const bool input_ready = fusable && draw && m->x_ready_gen == (const void *)p->gen && m->x_ready_step == nu.step;
+                m->x_ready_gen = nullptr;
                 // a redraw always comes with a recompute; the sampler update rides in the input kernel
-                int rc = generator_forward(p->gen, m->q, m->z, m->S, B, N, p->demean, st, draw ? &nu : nullptr);
+                int rc = generator_forward(p->gen, m->q, m->z, m->S, B, N, p->demean, st, draw ? &nu : nullptr,
+                                           fusable && !diag_due ? &gf : nullptr, input_ready);
                 if (rc) return rc;
                 m->have_forcing = true;
+                const bool white = (p->sampling == QGX_SAMPLING_AR1 && p->nsteps == 1) ||
+                                   (p->sampling == QGX_SAMPLING_CONSTANT && p->nsteps == 1);
+                if (fusable && white && !p->z_external_dev && s + 1 < nsteps) {
+                    if ((rc = generator_input_info(p->gen, B, N, &gf))) return rc;
+                    gf.z = (float *)m->z; gf.b = 1.f;
+                    gf.seed = p->seed; gf.member_offset = p->member_offset; gf.step = m->noise_step;
+                    m->x_ready_gen = p->gen; m->x_ready_step = m->noise_step;
+                }
+                use_gf = gf.y != nullptr || gf.X != nullptr;
             }
             has_S = m->have_forcing;
             S = m->S;
@@ -468,7 +490,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
             if (drc) return drc;
         }
         const int diag = (refresh_diag && s == nsteps - 1) ? 1 : 0;
-        int rc = model_step_once(m, has_S, S, weight, demean_in_kernel, diag, st);
+        int rc = model_step_once(m, has_S, S, weight, demean_in_kernel, diag, st, use_gf ? &gf : nullptr);
         if (rc) return rc;
     }
     return QGX_OK;

@@ -9,6 +9,7 @@
 // entirely inside one CU's LDS (N <= 96: N*(N+1)*16 B <= 149 KB).
 #include "common.hpp"
 #include "fft_lds.hpp"
+#include "philox.hpp"
 #include <cstdlib>
 
 namespace qgx {
@@ -130,10 +131,55 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     // ---- subgrid forcing: Sh_k = rfft2(weight * S_k), pair packed (pyqg _do_q_subgrid_parameterization)
     if (a.has_S) {
         const double *S0 = a.S + ro, *S1 = S0 + rz;
-        for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
-            const int y = idx / N, x = idx - y * N;
-            if (LSPLIT) Z[y * LD + x] = make_double2(a.weight * (kown ? S1 : S0)[idx], 0.);
-            else Z[y * LD + x] = make_double2(a.weight * S0[idx], a.weight * S1[idx]);
+        if (LSPLIT && a.gf.y) {
+            // the generator's output kernel folded in (k_finish<false>, conv.hip: same arithmetic, same summation order —
+            // 1024 threads, per-thread partial sums over u, wave shuffles, waves in order): S = double(y * y_std) - mean
+            constexpr int KEEP = 16;
+            __shared__ double fin_sm[16];
+            __shared__ double fin_mean;
+            const float *yk = a.gf.y + ((size_t)b * 2 + kown) * rz;
+            const float ys = a.gf.ys[kown];
+            double keep[KEEP];
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < KEEP; ++u) {
+                const int i = u * (int)blockDim.x + (int)threadIdx.x;
+                keep[u] = i < rz ? (double)(yk[i] * ys) : 0.0;
+                acc += keep[u];
+            }
+            double mu = 0.0;
+            if (a.gf.demean) {
+                for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+                if ((threadIdx.x & 63) == 0) fin_sm[threadIdx.x >> 6] = acc;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    double t = 0;
+                    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += fin_sm[w];
+                    fin_mean = t / (double)rz;
+                }
+                __syncthreads();
+                mu = fin_mean;
+            }
+            double *Sk = const_cast<double *>(kown ? S1 : S0);
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < KEEP; ++u) {
+                const int i = u * (int)blockDim.x + (int)threadIdx.x;
+                if (i < rz) {
+                    const double sv = keep[u] - mu;
+                    Sk[i] = sv;
+                    const int y = i / N, x = i - y * N;
+                    Z[y * LD + x] = make_double2(a.weight * sv, 0.);
+                }
+                bad |= !(fabs(keep[u]) <= 1.79e308);
+            }
+            if (bad) atomicOr(a.gf.range, 0x80000000u);      // a non-finite forcing never reaches the model unnoticed
+        } else {
+            for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+                const int y = idx / N, x = idx - y * N;
+                if (LSPLIT) Z[y * LD + x] = make_double2(a.weight * (kown ? S1 : S0)[idx], 0.);
+                else Z[y * LD + x] = make_double2(a.weight * S0[idx], a.weight * S1[idx]);
+            }
         }
         __syncthreads();
         fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
@@ -208,15 +254,41 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     else build_pair(Z, g, a.qh_out + so, a.qh_out + so + sz, d.invN2);
     __syncthreads();
     fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    float in_max = 0.f;
     for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
         const int y = idx / N, x = idx - y * N;
         const double2 w = Z[y * LD + x];
         if (LSPLIT) {
             a.q[ro + kown * rz + idx] = w.x;
+            if (a.gf.X) {       // the next step's network input, channel kown: float(q) / x_std (k_prep_noise, conv.hip)
+                const float xq = (float)w.x / a.gf.xs[kown];
+                a.gf.X[((size_t)b * 4 + kown) * rz + idx] = xq;
+                in_max = fmaxf(in_max, xq != xq ? __uint_as_float(0x7f800000u) : fabsf(xq));
+            }
         } else {
             a.q[ro + idx] = w.x;
             a.q[ro + rz + idx] = w.y;
         }
+    }
+    if (LSPLIT && a.gf.X) {
+        // ... and its latent channel kown: z = b * xi, white in time (k_prep_noise with a == 0; quads of the flat (2, N*N) field)
+        for (int ql = threadIdx.x; ql < rz / 4; ql += blockDim.x) {
+            const int quad = kown * (rz / 4) + ql;
+            float xi[4];
+            philox_normal4(a.gf.seed, a.gf.member_offset + b, a.gf.step, (uint32_t)quad, xi);
+            const size_t o = (size_t)b * 2 * rz + 4 * (size_t)quad;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float zn = a.gf.b * xi[e];
+                a.gf.z[o + e] = zn;
+                a.gf.X[(size_t)b * 4 * rz + 2 * (size_t)rz + 4 * (size_t)quad + e] = zn;
+                in_max = fmaxf(in_max, zn != zn ? __uint_as_float(0x7f800000u) : fabsf(zn));
+            }
+        }
+        // largest |network input| for the f16x3 range guard (input_absmax, conv.hip)
+        for (int o = 32; o > 0; o >>= 1) in_max = fmaxf(in_max, __shfl_down(in_max, o));
+        if ((threadIdx.x & 63) == 0 && __float_as_uint(in_max) > __builtin_nontemporal_load(a.gf.range + 1))
+            atomicMax(a.gf.range + 1, __float_as_uint(in_max));
     }
 }
 
@@ -335,7 +407,9 @@ int small_prepare(const SpecDev &d) {
 }
 
 // two workgroups per member (one per layer) while all of them are resident at once
-static bool layer_split(const SpecDev &d) {
+bool small_layer_split(const SpecDev &d);
+static bool layer_split(const SpecDev &d) { return small_layer_split(d); }
+bool small_layer_split(const SpecDev &d) {
     static const int forced = getenv("QGX_SPEC_LSPLIT") ? atoi(getenv("QGX_SPEC_LSPLIT")) : -1;   // tuning aid
     if (forced >= 0) return forced != 0;
     return 2 * d.B <= 256;      // one workgroup per CU (measured at 64x64: B = 128 44 -> 33 us, B = 256 55 -> 63 us)

@@ -317,6 +317,35 @@ def test_fused_step_noise_follows_pinned_philox_stream():
         assert np.abs(z1[m] - (a * x0 + b * x1)).max() < 4e-5
 
 
+
+@pytest.mark.parametrize('kind,N,B,sampling,nd', [('gan', 64, 4, 'AR1', 1), ('vae', 64, 1, 'constant', 1),
+                                                  ('vae', 96, 3, 'AR1', 1), ('gan', 48, 5, 'constant', 3),
+                                                  ('gan', 64, 2, 'AR1', 10)])
+def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B, sampling, nd):
+    """Layer-split small grids: the generator's output kernel rides in the step kernel's prologue and, for white-in-time
+    Philox noise, the next step's input kernel in its epilogue (GenFuse).  Same arithmetic in the same order: the run is
+    bit-identical to the one with separate kernels (QGX_NO_GENFUSE), diagnostics cadence and range words included."""
+    import pyqg_generative_amd._lib as L
+    q0 = _eddy_like_q(np.random.RandomState(7), B, N)
+    gen = _gpu_generator(kind)
+    res = []
+    for fused in (True, False):
+        if not fused:
+            os.environ['QGX_NO_GENFUSE'] = '1'
+        try:
+            e = _engine(N, B, dt=dt_for(N))
+            e.set_q(q0)
+            e.diag_config(0, 4)
+            for chunk in (7, 1, 5):
+                e.step(chunk, generator=gen, sampling=sampling, nsteps_decor=nd, seed=11, member_offset=3)
+            res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Z, L.F_Q)] + [e.diag('paramspec').clone(),
+                       torch.as_tensor(gen.range_read()[1])])
+            e.close()
+        finally:
+            os.environ.pop('QGX_NO_GENFUSE', None)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
 def test_full_size_step_members_are_independent():
     """BASELINE's single-GPU shard (128 members, 64 x 64, GAN): copies of four members spread over the
     ensemble, fed the same external noise, stay bit-identical through parameterized steps, and the
