@@ -126,6 +126,25 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
     const int sz = N * NK, rz = N * N;
     const double2 *qh0 = a.qh_in + so, *qh1 = qh0 + sz;
+    float in_max = 0.f;
+    if (LSPLIT && a.gf.X) {
+        // next step's latent channel first: it depends on nothing this kernel computes, and here its arithmetic
+        // (Philox rounds, log, sincos) runs while the first global loads of the step are in flight
+        // latent channel kown: z = b * xi, white in time (k_prep_noise with a == 0; quads of the flat (2, N*N) field)
+        for (int ql = threadIdx.x; ql < rz / 4; ql += blockDim.x) {
+            const int quad = kown * (rz / 4) + ql;
+            float xi[4];
+            philox_normal4(a.gf.seed, a.gf.member_offset + b, a.gf.step, (uint32_t)quad, xi);
+            const size_t o = (size_t)b * 2 * rz + 4 * (size_t)quad;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float zn = a.gf.b * xi[e];
+                a.gf.z[o + e] = zn;
+                a.gf.X[(size_t)b * 4 * rz + 2 * (size_t)rz + 4 * (size_t)quad + e] = zn;
+                in_max = fmaxf(in_max, zn != zn ? __uint_as_float(0x7f800000u) : fabsf(zn));
+            }
+        }
+    }
     __syncthreads();
 
     // ---- subgrid forcing: Sh_k = rfft2(weight * S_k), pair packed (pyqg _do_q_subgrid_parameterization)
@@ -254,7 +273,6 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     else build_pair(Z, g, a.qh_out + so, a.qh_out + so + sz, d.invN2);
     __syncthreads();
     fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
-    float in_max = 0.f;
     for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
         const int y = idx / N, x = idx - y * N;
         const double2 w = Z[y * LD + x];
@@ -271,20 +289,6 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
         }
     }
     if (LSPLIT && a.gf.X) {
-        // ... and its latent channel kown: z = b * xi, white in time (k_prep_noise with a == 0; quads of the flat (2, N*N) field)
-        for (int ql = threadIdx.x; ql < rz / 4; ql += blockDim.x) {
-            const int quad = kown * (rz / 4) + ql;
-            float xi[4];
-            philox_normal4(a.gf.seed, a.gf.member_offset + b, a.gf.step, (uint32_t)quad, xi);
-            const size_t o = (size_t)b * 2 * rz + 4 * (size_t)quad;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float zn = a.gf.b * xi[e];
-                a.gf.z[o + e] = zn;
-                a.gf.X[(size_t)b * 4 * rz + 2 * (size_t)rz + 4 * (size_t)quad + e] = zn;
-                in_max = fmaxf(in_max, zn != zn ? __uint_as_float(0x7f800000u) : fabsf(zn));
-            }
-        }
         // largest |network input| for the f16x3 range guard (input_absmax, conv.hip)
         for (int o = 32; o > 0; o >>= 1) in_max = fmaxf(in_max, __shfl_down(in_max, o));
         if ((threadIdx.x & 63) == 0 && __float_as_uint(in_max) > __builtin_nontemporal_load(a.gf.range + 1))
