@@ -100,8 +100,12 @@ __device__ __forceinline__ Grid make_grid(const SpecDev &d, double2 *Z, int *&po
     Grid g;
     g.N = d.N; g.NK = d.NK; g.LD = d.LD; g.nrad = d.nrad; g.rad = d.rad; g.tw = d.tw;
     pos_lds = reinterpret_cast<int *>(Z + d.N * d.LD);
-    for (int t = threadIdx.x; t < d.N; t += blockDim.x) pos_lds[t] = d.pos[t];
+    // twiddle table in LDS too: read from global memory, every butterfly of a transform's first pass waits for an
+    // L1 / L2 round trip (the large-grid kernels measured 60-70 % wait that way)
+    double2 *tw_lds = reinterpret_cast<double2 *>(pos_lds + ((d.N + 3) & ~3));
+    for (int t = threadIdx.x; t < d.N; t += blockDim.x) { pos_lds[t] = d.pos[t]; tw_lds[t] = d.tw[t]; }
     g.pos = pos_lds;
+    g.tw = tw_lds;
     return g;
 }
 
@@ -370,7 +374,7 @@ __global__ void k_invert_small(SpecDev d, const double2 *qh, double2 *ph, double
 
 // ------------------------------------------------------------------ host launchers
 static size_t small_lds_bytes(const SpecDev &d) {
-    size_t bytes = (size_t)d.N * d.LD * sizeof(double2) + (size_t)d.N * sizeof(int);
+    size_t bytes = (size_t)d.N * d.LD * sizeof(double2) + (size_t)((d.N + 3) & ~3) * sizeof(int) + (size_t)d.N * sizeof(double2);
     return (bytes + 15) & ~(size_t)15;
 }
 static int small_threads(const SpecDev &d) {
@@ -384,7 +388,8 @@ static int small_threads(const SpecDev &d) {
 }
 
 bool small_path_fits(int N) {
-    return (size_t)N * (N + 1) * 16 + (size_t)N * 4 + 16 <= 160 * 1024;
+    // field + digit-reversal table + twiddle table (small_lds_bytes) + the static reduction scratch of k_step_small
+    return (size_t)N * (N + 1) * 16 + (size_t)((N + 3) & ~3) * 4 + (size_t)N * 16 + 16 + 160 <= 160 * 1024;
 }
 
 // kernels specialised for the grid sizes the reference runs (compile-time index arithmetic and FFT
