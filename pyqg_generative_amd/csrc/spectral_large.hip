@@ -35,6 +35,7 @@ __global__ void k_lines_fft(SpecDev d, double2 *base, int k0, int nfpm, int LPB)
     double2 *g = base + ((size_t)(f / nfpm) * ZF + k0 + f % nfpm) * N * N;
     __syncthreads();
     // stage in: element e of line l -> L[l*LD + (FWD ? e : pos[e])]
+#pragma unroll 4
     for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
         int l, e;
         size_t go;
@@ -45,6 +46,7 @@ __global__ void k_lines_fft(SpecDev d, double2 *base, int k0, int nfpm, int LPB)
     __syncthreads();
     if (FWD) fft_lines_fwd(L, LPB, LD, 1, N, d.nrad, d.rad, twl);
     else fft_lines_inv(L, LPB, LD, 1, N, d.nrad, d.rad, twl);
+#pragma unroll 4
     for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
         int l, e;
         size_t go;
@@ -293,6 +295,7 @@ __global__ void k_l_rows_S(SpecDev d, const double *S, double2 *zbuf, double w, 
     const int groups = N / LPB;
     const int b = blockIdx.x / groups, j0 = (blockIdx.x - b * groups) * LPB;
     const double *S0 = S + (size_t)b * 2 * rz, *S1 = S0 + rz;
+#pragma unroll 4
     for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
         const int e = t % N, l = t / N;
         const size_t o = (size_t)(j0 + l) * N + e;
@@ -301,6 +304,7 @@ __global__ void k_l_rows_S(SpecDev d, const double *S, double2 *zbuf, double w, 
     __syncthreads();
     fft_lines_fwd(L, LPB, LD, 1, N, d.nrad, d.rad, twl);
     double2 *g = zbuf + ((size_t)b * ZF + 2) * N * N;
+#pragma unroll 4
     for (int t = threadIdx.x; t < LPB * N; t += blockDim.x) {
         const int e = t % N, l = t / N;
         g[(size_t)(j0 + l) * N + e] = L[l * LD + pos[e]];
@@ -323,6 +327,7 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
     const int b = f / nf, k = MODE == 0 ? f - b * nf : 2;
     double2 *g = zbuf + ((size_t)b * ZF + k) * N * N;
     __syncthreads();
+#pragma unroll 4
     for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
         const int r = t / CPB, c = t - r * CPB;
         L[c * LD + (MODE == 1 ? r : pos[r])] = g[(size_t)r * N + c0 + c];
@@ -336,6 +341,7 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
     if constexpr (MODE == 0) {
         const double Uk = d.U[k];
         const size_t ro = (size_t)b * 2 * rz + (size_t)k * rz;
+#pragma unroll 4
         for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
             const int r = t / CPB, c = t - r * CPB;
             const double2 uv = L[c * LD + r];
@@ -349,6 +355,7 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
     }
     if constexpr (MODE == 2) {
         double *q0 = q + (size_t)b * 2 * rz, *q1 = q0 + rz;
+#pragma unroll 4
         for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
             const int r = t / CPB, c = t - r * CPB;
             const double2 w = L[c * LD + r];
@@ -356,6 +363,7 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
             q1[(size_t)r * N + c0 + c] = w.y;
         }
     } else {
+#pragma unroll 4
         for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
             const int r = t / CPB, c = t - r * CPB;
             g[(size_t)r * N + c0 + c] = L[c * LD + pos[r]];
