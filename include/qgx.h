@@ -135,7 +135,8 @@ int qgx_step(qgx_model *m, int nsteps_to_run, const qgx_param *p, int refresh_di
 int64_t qgx_step_count(const qgx_model *m);
 int qgx_reset_time(qgx_model *m);
 
-/* status reductions of pyqg's _print_status: out_dev[2*b+0] = KE, [2*b+1] = CFL */
+/* status reductions of pyqg's _print_status: out_dev[2*b+0] = KE, [2*b+1] = CFL (of ph,u,v as the last step stored
+ * them; after steps with refresh_diag == 0 the current state is inverted first) */
 int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream);
 
 /* ---- time-averaged spectral diagnostics ------------------------------------------------

@@ -102,6 +102,7 @@ struct qgx_model {
     double2 *dq[3] = {nullptr, nullptr, nullptr};
     double2 *zbuf = nullptr;               // large-N path: (B,3,N,N) complex work array
     bool q_stale = false;                  // large-N path: q lags qh (unparameterized steps keep no real-space q)
+    bool uv_stale = false;                 // the last step did not store ph, u, v (refresh_diag == 0): status inverts first
     void *team_ctl = nullptr;              // large-N path: census / barrier block of the XCD-resident step kernel
     int team_state = 0;                    //   0 not probed, 1 available, -1 not available
     bool team_pending = false;             //   a run was launched whose flags have not been read back yet

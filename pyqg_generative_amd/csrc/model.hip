@@ -65,6 +65,7 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
     m->i_pp = m->i_p; m->i_p = m->i_new; m->i_new = dead;
     m->cur_q ^= 1;
     m->tc += 1;
+    m->uv_stale = diag == 0;
     return QGX_OK;
 }
 
@@ -83,6 +84,7 @@ static int model_step_run(qgx_model *m, int K, hipStream_t st) {
     m->cur_q ^= (K & 1);
     m->tc += K;
     m->ablevel = m->ablevel + K > 2 ? 2 : m->ablevel + K;
+    m->uv_stale = true;
     return QGX_OK;
 }
 
@@ -361,6 +363,7 @@ extern "C" int qgx_invert(qgx_model *m, void *stream) {
     if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m, "qgx_invert: null model");
     hipStream_t st = (hipStream_t)stream;
+    m->uv_stale = false;
     return m->small ? small_invert(m->d, m->qh[m->cur_q], m->ph, m->u, m->v, st) : large_invert(m, st);
 }
 
@@ -377,6 +380,12 @@ extern "C" int qgx_reset_time(qgx_model *m) {
 extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
     if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m && out_dev, "qgx_status_ke_cfl: null argument");
+    if (m->uv_stale) {
+        // the steps since the last refresh stored no ph, u, v: a status of stale (or never written) fields would be
+        // meaningless, so the CURRENT state is inverted first (pyqg reports the fields of its last _invert, one step back)
+        int irc = qgx_invert(m, stream);
+        if (irc) return irc;
+    }
     hipLaunchKernelGGL(k_status, dim3(m->B), dim3(256), 0, (hipStream_t)stream, m->d, m->ph, m->u, m->v, out_dev);
     QGX_HIP(hipGetLastError());
     return QGX_OK;
