@@ -133,6 +133,9 @@ typedef struct qgx_param {
 int qgx_step(qgx_model *m, int nsteps_to_run, const qgx_param *p, int refresh_diag, void *stream);
 /* step counter / ablevel (m.tc) and reset of the AB history */
 int64_t qgx_step_count(const qgx_model *m);
+/* 256 x 256 grids: 1 after the census found the device fit for the single-launch runs of qgx_step, -1 if it did not
+ * (or a run raised a flag), 0 before the first unparameterized step or on other grids */
+int qgx_run_kernel_state(const qgx_model *m);
 int qgx_reset_time(qgx_model *m);
 
 /* status reductions of pyqg's _print_status: out_dev[2*b+0] = KE, [2*b+1] = CFL (of ph,u,v as the last step stored

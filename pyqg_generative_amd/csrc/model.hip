@@ -368,6 +368,7 @@ extern "C" int qgx_invert(qgx_model *m, void *stream) {
 }
 
 extern "C" int64_t qgx_step_count(const qgx_model *m) { return m ? m->tc : -1; }
+extern "C" int qgx_run_kernel_state(const qgx_model *m) { return m ? m->team_state : 0; }
 
 extern "C" int qgx_reset_time(qgx_model *m) {
     QGX_REQUIRE(m, "qgx_reset_time: null model");

@@ -218,6 +218,12 @@ class EnsembleEngine:
     def tc(self):
         return int(lib.qgx_step_count(self._h))
 
+    @property
+    def run_kernel_state(self):
+        """256 x 256 grids: 1 = unparameterized runs of steps execute as single persistent launches, -1 = not on this
+        device (three launches per step), 0 = not decided yet / other grid"""
+        return int(lib.qgx_run_kernel_state(self._h))
+
     def reset_time(self):
         check(lib.qgx_reset_time(self._h))
 

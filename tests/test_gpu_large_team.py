@@ -167,6 +167,9 @@ def test_a_flag_raised_by_the_run_kernel_surfaces_at_the_next_call():
     import pyqg_generative_amd._lib as L
     e = _engine(8, dt=3600.)
     e.set_q(_eddy_like_q(np.random.RandomState(82), 8, 256))
+    e.step(3, refresh_diag=False)
+    if e.run_kernel_state != 1:
+        pytest.skip('the census did not find 8 x 32 co-resident workgroups on this device: three-launch path only')
     os.environ['QGX_TEAM_FAULT'] = '1'
     try:
         e.step(5, refresh_diag=False)              # launches asynchronously: no error yet
@@ -175,5 +178,5 @@ def test_a_flag_raised_by_the_run_kernel_surfaces_at_the_next_call():
     finally:
         del os.environ['QGX_TEAM_FAULT']
     e.step(4, refresh_diag=False)                  # the three-launch path from here on
-    assert e.tc == 9 and np.isfinite(e.get(L.F_QH).cpu().numpy()).all()
+    assert e.tc == 12 and e.run_kernel_state == -1 and np.isfinite(e.get(L.F_QH).cpu().numpy()).all()
     e.close()
