@@ -314,6 +314,7 @@ __global__ void k_l_rows_S(SpecDev d, const double *S, double2 *zbuf, double w, 
 // column tiles.  MODE 0: zbuf[b][k]: inverse along y, (u,v) -> ((u+U_k) q, v q), forward along y
 //                MODE 1: zbuf[b][2]: forward along y (forcing pair)
 //                MODE 2: zbuf[b][2]: inverse along y, real/imag parts -> q_1, q_2
+//                MODE 3: zbuf[b][k]: inverse along y, (u_k, v_k) stored — the inversion alone (large_invert)
 template <int MODE>
 __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double *v, int CPB) {
     double2 *L = reinterpret_cast<double2 *>(lg_smem);
@@ -322,9 +323,9 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
     double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));      // twiddle table in LDS, see lines_lds()
     for (int t = threadIdx.x; t < N; t += blockDim.x) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
     const int groups = N / CPB;
-    const int nf = MODE == 0 ? 2 : 1;
+    const int nf = (MODE == 0 || MODE == 3) ? 2 : 1;
     const int f = blockIdx.x / groups, c0 = (blockIdx.x - f * groups) * CPB;
-    const int b = f / nf, k = MODE == 0 ? f - b * nf : 2;
+    const int b = f / nf, k = (MODE == 0 || MODE == 3) ? f - b * nf : 2;
     double2 *g = zbuf + ((size_t)b * ZF + k) * N * N;
     __syncthreads();
 #pragma unroll 4
@@ -337,6 +338,17 @@ __global__ void k_l_cols(SpecDev d, double2 *zbuf, double *q, double *u, double 
         fft_lines_fwd(L, CPB, LD, 1, N, d.nrad, d.rad, twl);
     } else {
         fft_lines_inv(L, CPB, LD, 1, N, d.nrad, d.rad, twl);
+    }
+    if constexpr (MODE == 3) {
+        const size_t ro = (size_t)b * 2 * rz + (size_t)k * rz;
+#pragma unroll 4
+        for (int t = threadIdx.x; t < CPB * N; t += blockDim.x) {
+            const int r = t / CPB, c = t - r * CPB;
+            const double2 uv = L[c * LD + r];
+            const size_t o = ro + (size_t)r * N + c0 + c;
+            u[o] = uv.x; v[o] = uv.y;
+        }
+        return;
     }
     if constexpr (MODE == 0) {
         const double Uk = d.U[k];
@@ -537,7 +549,7 @@ int large_prepare(const SpecDev &d) {
                              (const void *)k_lines_fft<false, false>, (const void *)k_lines_fft<false, true>,
                              (const void *)k_l_rows_build_inv<0>, (const void *)k_l_rows_build_inv<1>,
                              (const void *)k_l_rows_build_inv<3>, (const void *)k_l_rows_S, (const void *)k_l_cols<0>,
-                             (const void *)k_l_cols<1>, (const void *)k_l_cols<2>, (const void *)k_l_cols3<>,
+                             (const void *)k_l_cols<1>, (const void *)k_l_cols<2>, (const void *)k_l_cols<3>, (const void *)k_l_cols3<>,
                              (const void *)k_l_rows_fwd_tend<>,
 #define QGX_L3(NN, P1, T1, C2, T2, P3, T3) (const void *)k_l_rows_build_inv<3, NN, P1, T1>, \
                    (const void *)k_l_cols3<NN, C2, T2>, (const void *)k_l_rows_fwd_tend<NN, P3, T3>
@@ -625,6 +637,21 @@ int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st) {
 
 int large_invert(qgx_model *m, hipStream_t st) {
     const SpecDev &d = m->d;
+    {
+        // fused form: (u, v) spectra built in the row kernel's staging (with psi stored), split into u, v in the column
+        // kernel's store — 2 launches instead of 4
+        const int lpb = lines_per_block(d.N);
+        static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+        if (!unfused && lpb >= 4 && lpb % 4 == 0 && (d.N / 2) % (lpb / 4) == 0 && d.N % lpb == 0) {
+            const size_t lds = lines_lds(d.N, lpb);
+            hipLaunchKernelGGL(k_l_rows_build_inv<0>, dim3(d.B * ((d.N / 2) / (lpb / 4))), dim3(256), lds, st, d,
+                               (const double2 *)m->qh[m->cur_q], m->zbuf, m->ph, lpb / 4, d.N);
+            hipLaunchKernelGGL(k_l_cols<3>, dim3(d.B * 2 * (d.N / lpb)), dim3(256), lds, st, d, m->zbuf, (double *)nullptr,
+                               m->u, m->v, lpb);
+            QGX_HIP(hipGetLastError());
+            return QGX_OK;
+        }
+    }
     hipLaunchKernelGGL(k_l_build_uv, pw_grid(d, d.N * d.NK), dim3(256), 0, st, d, m->qh[m->cur_q], m->zbuf, m->ph);
     int rc = fft2d_large<false>(d, m->zbuf, 0, 2, st);
     if (rc) return rc;
