@@ -81,6 +81,11 @@ struct StepArgs {
     GenFuse gf;
 };
 
+// time-averaged diagnostics (diag.hip; the small-grid increment is one kernel of spectral_small.hip)
+struct DiagConst { double del1, del2, rdm2, Udiff, rek, invM2, H0, H1; };
+struct DiagAcc { double *KEspec, *Ensspec, *entspec, *APEflux, *KEflux, *APEgenspec, *KEfrictionspec, *paramspec,
+                        *paramspec_APEflux, *paramspec_KEflux; };
+
 }  // namespace qgx
 
 struct qgx_generator;

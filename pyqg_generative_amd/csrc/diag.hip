@@ -8,6 +8,8 @@
 // All spectra carry pyqg's 1/M^2 normalisation.  PARITY UNPINNED (pyqg is not available here):
 // checked against oracle/qg_ref.py::_diag_functions only.
 #include "common.hpp"
+#include "diag_acc.hpp"
+#include <cstdlib>
 
 namespace qgx {
 int small_q_to_qh(const SpecDev &d, const double *q, double2 *qh, hipStream_t st);
@@ -16,8 +18,10 @@ int small_invert(const SpecDev &d, const double2 *qh, double2 *ph, double *u, do
 int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st);
 int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st);
 int large_invert(qgx_model *m, hipStream_t st);
+int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
+                         double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, const double *S, double weight,
+                         const DiagAcc &a, hipStream_t st);
 
-struct DiagConst { double del1, del2, rdm2, Udiff, rek, invM2, H0, H1; };
 
 // xih_k = -wv2 * ph_k
 __global__ void k_diag_xih(SpecDev d, const double2 *ph, double2 *xih) {
@@ -46,52 +50,15 @@ __global__ void k_diag_products(SpecDev d, DiagConst c, const double *u, const d
     }
 }
 
-struct DiagAcc { double *KEspec, *Ensspec, *entspec, *APEflux, *KEflux, *APEgenspec, *KEfrictionspec, *paramspec,
-                        *paramspec_APEflux, *paramspec_KEflux; };
-
 __global__ void k_diag_accumulate(SpecDev d, DiagConst c, const double2 *qh, const double2 *ph, const double2 *S3,
                                   const double2 *S4, const double2 *S5, const double2 *Sh, DiagAcc a) {
     const int N = d.N, NK = d.NK, sz = N * NK, b = blockIdx.y;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < sz; idx += gridDim.x * blockDim.x) {
         const int j = idx / NK, i = idx - j * NK;
         const size_t o = (size_t)b * 2 * sz + idx, o2 = (size_t)b * sz + idx;
-        const double kx = d.kk[i], ly = d.ll[j], wv2 = d.wv2[idx];
-        const double2 q1 = qh[o], q2 = qh[o + sz], p1 = ph[o], p2 = ph[o + sz];
-        a.KEspec[o] += wv2 * (p1.x * p1.x + p1.y * p1.y) * c.invM2;
-        a.KEspec[o + sz] += wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
-        a.Ensspec[o] += (q1.x * q1.x + q1.y * q1.y) * c.invM2;
-        a.Ensspec[o + sz] += (q2.x * q2.x + q2.y * q2.y) * c.invM2;
-        const double ex = c.del1 * q1.x + c.del2 * q2.x, ey = c.del1 * q1.y + c.del2 * q2.y;
-        a.entspec[o2] += (ex * ex + ey * ey) * c.invM2;
-        // Jptpc = -(ik A + il B), (A,B) = S3
-        const double2 A3 = S3[o], B3 = S3[o + sz];
-        const double jx = (kx * A3.y + ly * B3.y), jy = -(kx * A3.x + ly * B3.x);
-        const double dpx = p1.x - p2.x, dpy = p1.y - p2.y;
-        a.APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * jx + dpy * jy) * c.invM2;
-        // Jpxi_k = ik A + il B
-        const double2 A4 = S4[o], B4 = S4[o + sz], A5 = S5[o], B5 = S5[o + sz];
-        const double j1x = -(kx * A4.y + ly * B4.y), j1y = (kx * A4.x + ly * B4.x);
-        const double j2x = -(kx * A5.y + ly * B5.y), j2y = (kx * A5.x + ly * B5.x);
-        a.KEflux[o2] += (c.del1 * (p1.x * j1x + p1.y * j1y) + c.del2 * (p2.x * j2x + p2.y * j2y)) * c.invM2;
-        // APEgenspec = U rd^-2 del1 del2 Re[ i k (del1 p1 + del2 p2) conj(p1 - p2) ]
-        const double bx = c.del1 * p1.x + c.del2 * p2.x, by = c.del1 * p1.y + c.del2 * p2.y;
-        // i k (bx + i by) = (-k by, k bx); Re[(.)*conj(dp)] = (-k by) dpx + (k bx) dpy
-        a.APEgenspec[o2] += c.Udiff * c.rdm2 * c.del1 * c.del2 * kx * (bx * dpy - by * dpx) * c.invM2;
-        a.KEfrictionspec[o2] += -c.rek * c.del2 * wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
-        if (Sh) {
-            const double2 s1 = Sh[o], s2 = Sh[o + sz];
-            // -Re[ sum_k Hk/H conj(ph_k) dqh_k ]
-            a.paramspec[o2] += -(c.H0 * (p1.x * s1.x + p1.y * s1.y) + c.H1 * (p2.x * s2.x + p2.y * s2.y)) * c.invM2;
-            // its split into the available-potential and kinetic parts of the energy budget: with the streamfunction
-            // tendency of the parameterization dph = A dqh (the model's inversion),
-            //   paramspec_APEflux = rd^-2 del1 del2 Re[(p1 - p2) conj(dp1 - dp2)] / M^2
-            //   paramspec_KEflux  = wv2 sum_k del_k Re[p_k conj(dp_k)] / M^2,      APEflux + KEflux == paramspec
-            const double a00 = d.a[idx], a01 = d.a[sz + idx], a10 = d.a[2 * sz + idx], a11 = d.a[3 * sz + idx];
-            const double d1x = a00 * s1.x + a01 * s2.x, d1y = a00 * s1.y + a01 * s2.y;
-            const double d2x = a10 * s1.x + a11 * s2.x, d2y = a10 * s1.y + a11 * s2.y;
-            a.paramspec_APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * (d1x - d2x) + dpy * (d1y - d2y)) * c.invM2;
-            a.paramspec_KEflux[o2] += wv2 * (c.del1 * (p1.x * d1x + p1.y * d1y) + c.del2 * (p2.x * d2x + p2.y * d2y)) * c.invM2;
-        }
+        const double2 zero = make_double2(0., 0.);
+        diag_accumulate_elem(d, c, a, idx, i, j, o, o2, sz, qh[o], qh[o + sz], ph[o], ph[o + sz], S3[o], S3[o + sz], S4[o], S4[o + sz],
+                             S5[o], S5[o + sz], Sh != nullptr, Sh ? Sh[o] : zero, Sh ? Sh[o + sz] : zero);
     }
 }
 
@@ -126,6 +93,24 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
     double *p = m->dg_R[0], *xi = m->dg_R[1], *R3 = m->dg_R[2], *R4 = m->dg_R[3], *R5 = m->dg_R[4];
     double2 *xih = (double2 *)m->dg_S[0], *S3 = (double2 *)m->dg_S[1], *S4 = (double2 *)m->dg_S[2],
             *S5 = (double2 *)m->dg_S[3], *Sh = (double2 *)m->dg_S[4];
+    static const bool unfused = getenv("QGX_DIAG_UNFUSED") != nullptr;       // A/B aid
+    if (m->small && !unfused) {
+        // small grids: the whole increment (inversion, eight packed transforms, products, accumulation) in ONE kernel, a
+        // workgroup per member (spectral_small.hip::k_diag_small) instead of nine launches
+        DiagConst c;
+        c.del1 = m->cfg.delta / (m->cfg.delta + 1.); c.del2 = 1. / (m->cfg.delta + 1.);
+        c.rdm2 = pow(m->cfg.rd, -2.0); c.Udiff = m->cfg.U1 - m->cfg.U2; c.rek = m->cfg.rek;
+        c.invM2 = d.invN2 * d.invN2; c.H0 = d.H[0] / d.Htot; c.H1 = d.H[1] / d.Htot;
+        DiagAcc a;
+        a.KEspec = m->dg_acc[0]; a.Ensspec = m->dg_acc[1]; a.entspec = m->dg_acc[2]; a.APEflux = m->dg_acc[3];
+        a.KEflux = m->dg_acc[4]; a.APEgenspec = m->dg_acc[5]; a.KEfrictionspec = m->dg_acc[6]; a.paramspec = m->dg_acc[7];
+        a.paramspec_APEflux = m->dg_acc[8]; a.paramspec_KEflux = m->dg_acc[9];
+        rc = small_diag_increment(d, c, qh, m->ph, m->u, m->v, p, xi, S3, S4, S5, Sh, S, weight, a, st);
+        if (rc) return rc;
+        m->uv_stale = false;
+        m->dg_count += 1;
+        return QGX_OK;
+    }
     // _invert: ph, u, v of the current state
     rc = m->small ? small_invert(d, qh, m->ph, m->u, m->v, st) : large_invert(m, st);
     if (rc) return rc;

@@ -1,0 +1,47 @@
+// One spectral element of model.py::_increment_diagnostics (shared by diag.hip::k_diag_accumulate and
+// spectral_small.hip::k_diag_small): the ten time-averaged diagnostics, pyqg's 1/M^2 normalisation.
+#pragma once
+#include "common.hpp"
+
+namespace qgx {
+
+__device__ __forceinline__ void diag_accumulate_elem(const SpecDev &d, const DiagConst &c, const DiagAcc &a, int idx, int i, int j,
+                                                     size_t o, size_t o2, int sz, double2 q1, double2 q2, double2 p1, double2 p2,
+                                                     double2 A3, double2 B3, double2 A4, double2 B4, double2 A5, double2 B5,
+                                                     bool has_S, double2 s1, double2 s2) {
+    const double kx = d.kk[i], ly = d.ll[j], wv2 = d.wv2[idx];
+    a.KEspec[o] += wv2 * (p1.x * p1.x + p1.y * p1.y) * c.invM2;
+    a.KEspec[o + sz] += wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
+    a.Ensspec[o] += (q1.x * q1.x + q1.y * q1.y) * c.invM2;
+    a.Ensspec[o + sz] += (q2.x * q2.x + q2.y * q2.y) * c.invM2;
+    const double ex = c.del1 * q1.x + c.del2 * q2.x, ey = c.del1 * q1.y + c.del2 * q2.y;
+    a.entspec[o2] += (ex * ex + ey * ey) * c.invM2;
+    // Jptpc = -(ik A + il B), (A,B) = S3
+    const double jx = (kx * A3.y + ly * B3.y), jy = -(kx * A3.x + ly * B3.x);
+    const double dpx = p1.x - p2.x, dpy = p1.y - p2.y;
+    a.APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * jx + dpy * jy) * c.invM2;
+    // Jpxi_k = ik A + il B
+    const double j1x = -(kx * A4.y + ly * B4.y), j1y = (kx * A4.x + ly * B4.x);
+    const double j2x = -(kx * A5.y + ly * B5.y), j2y = (kx * A5.x + ly * B5.x);
+    a.KEflux[o2] += (c.del1 * (p1.x * j1x + p1.y * j1y) + c.del2 * (p2.x * j2x + p2.y * j2y)) * c.invM2;
+    // APEgenspec = U rd^-2 del1 del2 Re[ i k (del1 p1 + del2 p2) conj(p1 - p2) ]
+    const double bx = c.del1 * p1.x + c.del2 * p2.x, by = c.del1 * p1.y + c.del2 * p2.y;
+    // i k (bx + i by) = (-k by, k bx); Re[(.)*conj(dp)] = (-k by) dpx + (k bx) dpy
+    a.APEgenspec[o2] += c.Udiff * c.rdm2 * c.del1 * c.del2 * kx * (bx * dpy - by * dpx) * c.invM2;
+    a.KEfrictionspec[o2] += -c.rek * c.del2 * wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
+    if (has_S) {
+        // -Re[ sum_k Hk/H conj(ph_k) dqh_k ]
+        a.paramspec[o2] += -(c.H0 * (p1.x * s1.x + p1.y * s1.y) + c.H1 * (p2.x * s2.x + p2.y * s2.y)) * c.invM2;
+        // its split into the available-potential and kinetic parts of the energy budget: with the streamfunction
+        // tendency of the parameterization dph = A dqh (the model's inversion),
+        //   paramspec_APEflux = rd^-2 del1 del2 Re[(p1 - p2) conj(dp1 - dp2)] / M^2
+        //   paramspec_KEflux  = wv2 sum_k del_k Re[p_k conj(dp_k)] / M^2,      APEflux + KEflux == paramspec
+        const double a00 = d.a[idx], a01 = d.a[sz + idx], a10 = d.a[2 * sz + idx], a11 = d.a[3 * sz + idx];
+        const double d1x = a00 * s1.x + a01 * s2.x, d1y = a00 * s1.y + a01 * s2.y;
+        const double d2x = a10 * s1.x + a11 * s2.x, d2y = a10 * s1.y + a11 * s2.y;
+        a.paramspec_APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * (d1x - d2x) + dpy * (d1y - d2y)) * c.invM2;
+        a.paramspec_KEflux[o2] += wv2 * (c.del1 * (p1.x * d1x + p1.y * d1y) + c.del2 * (p2.x * d2x + p2.y * d2y)) * c.invM2;
+    }
+}
+
+}  // namespace qgx

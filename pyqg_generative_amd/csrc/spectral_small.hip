@@ -10,6 +10,7 @@
 #include "common.hpp"
 #include "fft_lds.hpp"
 #include "philox.hpp"
+#include "diag_acc.hpp"
 #include <cstdlib>
 
 namespace qgx {
@@ -372,6 +373,110 @@ __global__ void k_invert_small(SpecDev d, const double2 *qh, double2 *ph, double
     }
 }
 
+// ------------------------------------------------------------------ one increment of the time-averaged diagnostics
+// model.py::_calc_diagnostics on the small grids, a workgroup per member: _invert (psi, u, v of the current state),
+// p = irfft2(psi), xi = irfft2(-K^2 psi), the three pairs of real-space products, their transforms and the forcing's,
+// accumulation — what diag.hip runs as nine launches on the large grids.  Real-space fields pass through the model's own
+// arrays (u, v: kept, as _invert leaves them) and two scratch arrays; every global value is re-read by the thread that
+// wrote it or after a workgroup barrier.  The arithmetic is that of k_invert_small, k_qh_to_q_small, k_diag_xih,
+// k_diag_products, k_q_to_qh_small, k_diag_scale_S and k_diag_accumulate, expression by expression.
+template <int NN>
+__global__ void k_diag_small(SpecDev d, DiagConst c, const double2 *qh, double2 *ph, double *u, double *v, double *P, double *XI,
+                             double2 *S3, double2 *S4, double2 *S5, double2 *Sh, const double *S, double weight, DiagAcc acc) {
+    double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
+    int *pos_lds;
+    Grid g = make_grid(d, Z, pos_lds);
+    if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
+    const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD, b = blockIdx.x;
+    const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
+    const int sz = N * NK, rz = N * N;
+    __syncthreads();
+    // ---- _invert
+    for (int k = 0; k < 2; ++k) {
+        build_uv(Z, g, d, k, qh + so, qh + so + sz, ph + so + k * sz);
+        __syncthreads();
+        fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+        for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+            const int y = idx / N, x = idx - y * N;
+            const double2 uv = Z[y * LD + x];
+            u[ro + k * rz + idx] = uv.x;
+            v[ro + k * rz + idx] = uv.y;
+        }
+        __syncthreads();
+    }
+    // ---- p = irfft2(psi), both layers as one packed pair
+    build_pair(Z, g, ph + so, ph + so + sz, d.invN2);
+    __syncthreads();
+    fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+        const int y = idx / N, x = idx - y * N;
+        const double2 w = Z[y * LD + x];
+        P[ro + idx] = w.x;
+        P[ro + rz + idx] = w.y;
+    }
+    __syncthreads();
+    // ---- xi = irfft2(-K^2 psi): the spectrum goes through S3 (free until the first product transform)
+    for (int idx = threadIdx.x; idx < 2 * sz; idx += blockDim.x) {
+        const double w = -d.wv2[idx % sz];
+        const double2 p = ph[so + idx];
+        S3[so + idx] = make_double2(w * p.x, w * p.y);
+    }
+    __syncthreads();
+    build_pair(Z, g, S3 + so, S3 + so + sz, d.invN2);
+    __syncthreads();
+    fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+        const int y = idx / N, x = idx - y * N;
+        const double2 w = Z[y * LD + x];
+        XI[ro + idx] = w.x;
+        XI[ro + rz + idx] = w.y;
+    }
+    __syncthreads();
+    // ---- the three pairs of products and the forcing, each: stage the pair, forward transform, unpack
+    for (int which = 0; which < 4; ++which) {
+        if (which == 3 && !S) break;
+        for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+            const int y = idx / N, x = idx - y * N;
+            const size_t o = ro + idx;
+            double ra, rb;
+            if (which == 0) {
+                const double u1 = u[o], u2 = u[o + rz], v1 = v[o], v2 = v[o + rz];
+                const double ptpc = P[o] - P[o + rz];
+                const double ub = c.del1 * u1 + c.del2 * u2, vb = c.del1 * v1 + c.del2 * v2;
+                ra = ub * ptpc; rb = vb * ptpc;
+            } else if (which == 1) {
+                const double x1 = XI[o];
+                ra = u[o] * x1; rb = v[o] * x1;
+            } else if (which == 2) {
+                const double x2 = XI[o + rz];
+                ra = u[o + rz] * x2; rb = v[o + rz] * x2;
+            } else {
+                ra = weight * S[o]; rb = weight * S[o + rz];
+            }
+            Z[y * LD + x] = make_double2(ra, rb);
+        }
+        __syncthreads();
+        fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+        double2 *dst = which == 0 ? S3 : (which == 1 ? S4 : (which == 2 ? S5 : Sh));
+        for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
+            const int j = idx / NK, i = idx - j * NK;
+            double2 s0, s1;
+            unpack_pair(Z, g, j, i, s0, s1);
+            dst[so + idx] = s0;
+            dst[so + sz + idx] = s1;
+        }
+        __syncthreads();
+    }
+    // ---- accumulate (each thread re-reads the transforms it unpacked itself)
+    for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
+        const int j = idx / NK, i = idx - j * NK;
+        const size_t o = so + idx, o2 = (size_t)b * sz + idx;
+        const double2 zero = make_double2(0., 0.);
+        diag_accumulate_elem(d, c, acc, idx, i, j, o, o2, sz, qh[o], qh[o + sz], ph[o], ph[o + sz], S3[o], S3[o + sz], S4[o], S4[o + sz],
+                             S5[o], S5[o + sz], S != nullptr, S ? Sh[o] : zero, S ? Sh[o + sz] : zero);
+    }
+}
+
 // ------------------------------------------------------------------ host launchers
 static size_t small_lds_bytes(const SpecDev &d) {
     size_t bytes = (size_t)d.N * d.LD * sizeof(double2) + (size_t)((d.N + 3) & ~3) * sizeof(int) + (size_t)d.N * sizeof(double2);
@@ -411,6 +516,7 @@ int small_prepare(const SpecDev &d) {
         QGX_HIP(hipFuncSetAttribute((const void *)k_q_to_qh_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_qh_to_q_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        QGX_HIP(hipFuncSetAttribute((const void *)k_diag_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     })
     return QGX_OK;
 }
@@ -445,6 +551,14 @@ int small_qh_to_q(const SpecDev &d, const double2 *qh, double *q, hipStream_t st
 }
 int small_invert(const SpecDev &d, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st) {
     QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_invert_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, qh, ph, u, v))
+    QGX_HIP(hipGetLastError());
+    return QGX_OK;
+}
+int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
+                         double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, const double *S, double weight,
+                         const DiagAcc &a, hipStream_t st) {
+    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_diag_small<NN>, dim3(d.B), dim3(1024), small_lds_bytes(d), st, d, c, qh, ph, u, v, P, XI,
+                                           S3, S4, S5, Sh, S, weight, a))
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
