@@ -324,27 +324,33 @@ def test_fused_step_noise_follows_pinned_philox_stream():
 def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B, sampling, nd):
     """Layer-split small grids: the generator's output kernel rides in the step kernel's prologue and, for white-in-time
     Philox noise, the next step's input kernel in its epilogue (GenFuse).  Same arithmetic in the same order: the run is
-    bit-identical to the one with separate kernels (QGX_NO_GENFUSE), diagnostics cadence and range words included."""
+    bit-identical to the one with separate kernels (QGX_NO_GENFUSE), diagnostics cadence and range words included.
+    Likewise the diagnostics increment: one kernel per member against the nine launches of diag.hip."""
     import pyqg_generative_amd._lib as L
     q0 = _eddy_like_q(np.random.RandomState(7), B, N)
     gen = _gpu_generator(kind)
     res = []
-    for fused in (True, False):
-        if not fused:
-            os.environ['QGX_NO_GENFUSE'] = '1'
+    # default / separate generator kernels / nine-launch diagnostics increment
+    for env in (None, 'QGX_NO_GENFUSE', 'QGX_DIAG_UNFUSED'):
+        if env:
+            os.environ[env] = '1'
         try:
             e = _engine(N, B, dt=dt_for(N))
             e.set_q(q0)
             e.diag_config(0, 4)
             for chunk in (7, 1, 5):
                 e.step(chunk, generator=gen, sampling=sampling, nsteps_decor=nd, seed=11, member_offset=3)
-            res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Z, L.F_Q)] + [e.diag('paramspec').clone(),
-                       torch.as_tensor(gen.range_read()[1])])
+            res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Z, L.F_Q, L.F_U, L.F_PH)] +
+                       [e.diag(n).clone() for n in ('paramspec', 'KEspec', 'KEflux', 'APEflux', 'paramspec_KEflux')] +
+                       [torch.as_tensor(gen.range_read()[1]), torch.as_tensor(e.diag_count)])
             e.close()
         finally:
-            os.environ.pop('QGX_NO_GENFUSE', None)
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+            if env:
+                os.environ.pop(env, None)
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+
 
 def test_full_size_step_members_are_independent():
     """BASELINE's single-GPU shard (128 members, 64 x 64, GAN): copies of four members spread over the
