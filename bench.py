@@ -16,10 +16,16 @@ of the path: an all-reduce of per-rank partial sums).  Members are sharded over 
 data-path collective (weak scaling: --members per GPU is fixed; 128/GPU = BASELINE configs[2]'s
 1024 members on 8 GPUs).  Rank 0 prints ONE JSON line.
 
-Auxiliary legs on one GPU (same JSON line): `exact_f32` (the same workload on the f32 matrix cores),
-`b1` (configs[1]: one member), `config3` (96x96 jet + CVAE, 32 members = configs[3]'s per-GPU shard),
-`config4` (256x256 unparameterized, 64 members, with a coarse-grain + subgrid-forcing diagnostic to
-64x64 per snapshot = configs[4]), `cpu_baseline` (the CPU oracle on this box's host cores).
+Auxiliary legs on one GPU (same JSON line), each with its OWN fixed protocol, independent of --steps:
+`steady` (the headline workload under SURVEY §8d's protocol: 100 warm-up + 2,000 timed steps, 8 snapshots and 2 status
+checks inside, >= 200 event-bracketed launches of the roofline kernel), `exact_f32` (the same workload on the f32 matrix
+cores), `b1` (configs[1]: one member), `b1024` (configs[2] WHOLE on one GPU: 1024 members, the one-workgroup-per-member
+step kernel), `config3` (96x96 jet + CVAE, 32 members = configs[3]'s per-GPU shard), `config4` (256x256
+unparameterized, 64 members: 1000 steps = one snapshot interval of a forcing-dataset run, pyqg's time-averaged
+diagnostics every 24 steps in the second half, ONE coarse-grain + subgrid-forcing diagnostic to 64x64, all timed),
+`cpu_baseline` (the CPU oracle on this box's host cores).
+
+    --total-members M    strong scaling: ONE M-member ensemble split over the ranks (M / world each)
 """
 import argparse
 import json
@@ -129,7 +135,13 @@ def timed(fn, barrier=lambda: None):
     return time.perf_counter() - t0
 
 
-def mfma_roofline(gen, precision, N, B, kname, traffic):
+def prof_stride(K):
+    """HIP events around every n-th launch of the roofline kernel (a pair idles the GPU for ~12 us): every 10th in a
+    long run, denser in a short one so that even the driver's 20-step run brackets 10 launches"""
+    return 10 if K >= 1000 else (5 if K >= 200 else 2)
+
+
+def mfma_roofline(gen, precision, N, B, kname, traffic, stride=10):
     """roofline object of the dominant kernel (generator layer 2: 75 % of the FLOPs) from the HIP events the
     library recorded around its launches inside the timed region"""
     ms, n = gen.profile_read()
@@ -140,7 +152,7 @@ def mfma_roofline(gen, precision, N, B, kname, traffic):
     peak = F32_MFMA_PEAK_TFLOPS if precision == 'f32' else F16_MFMA_PEAK_TFLOPS
     r = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
          'frac': achieved / peak, 'traffic': traffic, 'flop_per_launch': flop, 'avg_launch_ms': avg_s * 1e3,
-         'launches_timed': n, 'launches_timed_note': 'HIP events bracket every 10th launch of the timed region',
+         'launches_timed': n, 'launches_timed_note': f'HIP events bracket every {stride}th launch of the timed region',
          'peak_note': ('dense f32 MFMA peak; ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)' if precision == 'f32'
                        else 'dense f16 MFMA peak; `achieved` counts ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)')}
     if precision == 'f16x3':
@@ -204,8 +216,8 @@ def cpu_baseline(N, kind, dt, target_seconds=15.0):
                 one_core=r1, cores_share=share, share_rate=rm)
 
 
-def leg_config3(qa, device, K, W):
-    """BASELINE configs[3]'s per-GPU shard: 96x96 jet + CVAE decoder, 32 members."""
+def leg_config3(qa, device, K=200, W=10):
+    """BASELINE configs[3]'s per-GPU shard: 96x96 jet + CVAE decoder, 32 members; 200 timed steps."""
     N, B = 96, 32
     dt = dt_of(N)
     gen, _ = load_generator('vae', device)
@@ -213,11 +225,11 @@ def leg_config3(qa, device, K, W):
     eng.set_q(eddy_like_q(np.arange(B), N))
     loop = OnlineLoop(eng, dt, dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024))
     loop.run(W)
-    gen.set_option('prof_every', 10)
+    gen.set_option('prof_every', prof_stride(K))
     gen.profile(1)
     el = timed(lambda: loop.run(K))
     roof = mfma_roofline(gen, 'f16x3', N, B, 'k_convh2<128,64,5x5> at 96x96 (generator layer 2)',
-                         pmc_traffic('pmc_traffic_config3.json', {'nx': N, 'members_per_gpu': B, 'kind': 'vae'}))
+                         pmc_traffic('pmc_traffic_config3.json', {'nx': N, 'members_per_gpu': B, 'kind': 'vae'}), prof_stride(K))
     ke, cfl = eng.status()
     out = {'workload': f'BASELINE configs[3] shard: jet {N}x{N} + CVAE, {B} members on 1 GPU (256 members / 8 GPUs), '
                        f"sampling='constant' nsteps=1, dt={dt:.0f}s",
@@ -230,15 +242,20 @@ def leg_config3(qa, device, K, W):
     return out
 
 
-def leg_config4(qa, device, K, W):
-    """BASELINE configs[4]: 256x256 unparameterized hires members + the coarse-grain / subgrid-forcing
-    diagnostic to 64x64 (Operator2 and Operator5, 3/2-rule: simulate.py:88-92) at every snapshot."""
+def leg_config4(qa, device, K=1000, W=24):
+    """BASELINE configs[4]: 256x256 unparameterized hires members + the coarse-grain / subgrid-forcing diagnostic to
+    64x64 (Operator2 and Operator5, 3/2-rule: simulate.py:88-92) once per snapshot interval.  The timed region IS one
+    snapshot interval of a forcing-dataset run in its averaging half (run_forcing_datasets.py:17-25: tavestart = half
+    of the run): K = ceil(3.6e6/dt) = 1000 steps, pyqg's time-averaged diagnostics every ceil(86400/dt) = 24 steps
+    during the second half of them, and ONE coarse-grain at the end — nothing extrapolated."""
     from pyqg_generative_amd.tools.operators import Dev
     from pyqg_generative_amd import _lib
     N, B, nc = 256, 64, 64
     dt = dt_of(N)
+    every = int(math.ceil(86400. / dt))
     eng = qa.EnsembleEngine(nx=N, n_members=B, device=device, dt=dt)
     eng.set_q(eddy_like_q(np.arange(B), N))
+    eng.diag_config(W + K // 2, every)              # tavestart in the middle of the timed interval
     eng.step(W)
     pp = dict(qa.engine.PYQG_DEFAULTS)
 
@@ -248,33 +265,68 @@ def leg_config4(qa, device, K, W):
         for op in (Dev.Operator2, Dev.Operator5):
             Dev.subgrid_forcing_from_hat(qh, adv_hat, nc, op, pp, '3/2-rule')
     coarsegrain()                                   # plan creation outside the timed region
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]   # qgx_step launches on torch's current stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]   # qgx_step launches on torch's current stream
 
     def body():
         ev[0].record()
-        eng.step(K)
+        eng.step(K // 2)                            # spin-up half: no diagnostics
         ev[1].record()
+        eng.step(K - K // 2)                        # averaging half: one increment every `every` steps
+        ev[2].record()
         coarsegrain()
+        ev[3].record()
     el = timed(body)
-    step_ms = ev[0].elapsed_time(ev[1]) / K
+    plain_ms = ev[0].elapsed_time(ev[1]) / (K // 2)
+    diag_ms = ev[1].elapsed_time(ev[2]) / (K - K // 2)
+    step_ms = ev[0].elapsed_time(ev[2]) / K
+    cg_ms = ev[2].elapsed_time(ev[3])
     bytes_step = 5 * (2 * N * (N // 2 + 1) * 16) * B           # 5,283,840 B per member-step
     achieved = bytes_step / (step_ms * 1e-3) / 1e9
-    snap = int(math.ceil(3.6e6 / dt))
     ke, cfl = eng.status()
-    out = {'workload': f'BASELINE configs[4]: eddy {N}x{N} unparameterized, {B} members on 1 GPU, dt={dt:.0f}s; one '
-                       f'coarse-grain + 3/2-rule subgrid forcing to {nc}x{nc} (Operator2, Operator5) after the {K} timed steps',
-           'value': B * K / el, 'unit': 'ensemble-timesteps/sec (coarse-grain included once per timed run)',
-           'steps': K, 'ms_per_step': step_ms, 'coarsegrain_ms': 1e3 * el - step_ms * K,
-           'value_at_reference_cadence': B * snap / (step_ms * 1e-3 * snap + (el - step_ms * 1e-3 * K)),
-           'cadence_note': f'reference cadence: one coarse-grain per {snap} steps',
-           'roofline': {'bound': 'hbm', 'kernel': 'spectral step (spectral_large.hip: XCD-resident run kernel k_l_team_steps + one three-launch step per call)',
+    out = {'workload': f'BASELINE configs[4]: eddy {N}x{N} unparameterized, {B} members on 1 GPU, dt={dt:.0f}s; {K} steps = one '
+                       f'snapshot interval, time-averaged diagnostics every {every} steps in its second half '
+                       f'({eng.diag_count} increments), then one coarse-grain + 3/2-rule subgrid forcing to {nc}x{nc} '
+                       '(Operator2, Operator5) — all inside the timed region',
+           'value': B * K / el, 'unit': 'ensemble-timesteps/sec', 'steps': K, 'ms_per_step': step_ms,
+           'ms_per_step_without_diagnostics': plain_ms, 'ms_per_step_with_diagnostics_cadence': diag_ms,
+           'coarsegrain_ms': cg_ms, 'diagnostic_increments': eng.diag_count, 'run_kernel_state': eng.run_kernel_state,
+           'roofline': {'bound': 'hbm', 'kernel': 'spectral step (spectral_large.hip: XCD-resident run kernel k_l_team_steps between '
+                                                  'diagnostics increments + one three-launch step per call)',
                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                         'traffic': pmc_traffic('pmc_traffic_config4.json', {'nx': N, 'members': B}),
                         'bytes_per_step': bytes_step, 'avg_step_ms': step_ms,
-                        'peak_note': 'ALGORITHMIC bytes: read qh, dqhdt_p, dqhdt_pp + write qh, dqhdt = 5 x (2 N nk 16 B) per member-step'},
+                        'frac_without_diagnostics': bytes_step / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        'peak_note': 'ALGORITHMIC bytes: read qh, dqhdt_p, dqhdt_pp + write qh, dqhdt = 5 x (2 N nk 16 B) per '
+                                     'member-step; avg_step_ms averages BOTH halves (with the diagnostics cadence in the second)'},
            'healthy': bool(np.isfinite(ke).all() and (cfl < 1).all())}
     eng.close()
     Dev.close()
+    return out
+
+
+def leg_members(qa, device, gen, B, K, W, name, note):
+    """the headline workload with another resident member count (1: configs[1]; 1024: configs[2] whole on one GPU)"""
+    N = 64
+    dt = dt_of(N)
+    e = qa.EnsembleEngine(nx=N, n_members=B, device=device, dt=dt)
+    e.set_q(eddy_like_q(np.arange(B), N))
+    loop = OnlineLoop(e, dt, dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024, member_offset=0))
+    loop.run(W)
+    gen.set_option('prof_every', prof_stride(K))
+    gen.profile(1)
+    n0 = (loop.nsnap, loop.nstatus)
+    el = timed(lambda: loop.run(K))
+    out = {'workload': note, 'value': B * K / el, 'unit': 'ensemble-timesteps/sec', 'steps': K, 'warmup': W,
+           'ms_per_step': 1e3 * el / K, 'snapshots_in_timed_region': loop.nsnap - n0[0],
+           'status_checks_in_timed_region': loop.nstatus - n0[1]}
+    if B >= 8:
+        out['roofline'] = mfma_roofline(gen, 'f16x3', N, B, 'k_convh2<128,64,5x5> (generator layer 2)', None, prof_stride(K))
+    else:
+        gen.profile_read()
+        gen.profile(-1)
+    ke, cfl = e.status()
+    out['healthy'] = bool(np.isfinite(ke).all() and (cfl < 1).all())
+    e.close()
     return out
 
 
@@ -283,15 +335,17 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000, help='timed steps (SURVEY §8d: 2,000 after 100 warm-up)')
     ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--members', type=int, default=128, help='ensemble members PER GPU')
+    ap.add_argument('--members', type=int, default=128, help='ensemble members PER GPU (weak scaling)')
+    ap.add_argument('--total-members', type=int, default=0,
+                    help='strong scaling: ONE ensemble of this many members split over the ranks (overrides --members)')
     ap.add_argument('--nx', type=int, default=64)
     ap.add_argument('--kind', default='gan', choices=['gan', 'vae', 'gz'])
     ap.add_argument('--precision', default='f16x3', choices=list(PRECISIONS),
                     help='generator conv arithmetic: f16x3 = hi/lo split f16 MFMA, f32-class accuracy (default); '
                          'f32 = exact f32 MFMA')
-    ap.add_argument('--no-aux', action='store_true', help='skip exact_f32 / b1 / config3 / config4 legs')
+    ap.add_argument('--no-aux', action='store_true', help='skip the steady / exact_f32 / b1 / b1024 / config3 / config4 legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--leg', default='all', choices=['all', 'config3', 'config4'],
+    ap.add_argument('--leg', default='all', choices=['all', 'config3', 'config4', 'b1', 'b1024'],
                     help='profiling runs: only the named auxiliary leg (prints its JSON object)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + QGX_BENCH_ONE_DEVICE=1 rehearses the multi-rank path on a 1-GPU box")
@@ -316,19 +370,35 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
 
     import pyqg_generative_amd as qa
-    N, B, K, W = args.nx, args.members, args.steps, args.warmup
+    from pyqg_generative_amd import parallel
+    N, K, W = args.nx, args.steps, args.warmup
+    B1 = 'BASELINE configs[1]: 64x64 eddy + CGAN, 1 member on 1 GPU (launch-latency-bound)'
+    B1024 = ('BASELINE configs[2] WHOLE on one GPU: 64x64 eddy + CGAN, 1024 members (one workgroup per member in the '
+             'spectral step, k_step_small<64,false> at 512 threads)')
     if args.leg != 'all':
-        leg = {'config3': leg_config3, 'config4': leg_config4}[args.leg]
-        print(json.dumps({args.leg: leg(qa, local_rank, K, W)}))
+        if args.leg in ('config3', 'config4'):
+            res = {'config3': leg_config3, 'config4': leg_config4}[args.leg](qa, local_rank)
+        else:
+            g, _ = load_generator(args.kind, local_rank)
+            res = leg_members(qa, local_rank, g, *{'b1': (1, 2000, 100, 'b1', B1), 'b1024': (1024, 250, 10, 'b1024', B1024)}[args.leg])
+        print(json.dumps({args.leg: res}))
         return
     dt = dt_of(N)
+    strong = args.total_members > 0
+    if strong:
+        first, B = parallel.shard_members(args.total_members, rank, world)      # contiguous blocks, sizes differ by <= 1
+        total_members = args.total_members
+        if B < 1:
+            raise SystemExit(f'--total-members {args.total_members} leaves rank {rank} of {world} without a member')
+    else:
+        B = args.members
+        first, total_members = rank * B, B * world
     gen, wsrc = load_generator(args.kind, local_rank)
     gen.set_option('precision', PRECISIONS[args.precision])
     eng = qa.EnsembleEngine(nx=N, n_members=B, device=local_rank, dt=dt)
-    ids = np.arange(rank * B, (rank + 1) * B)
-    eng.set_q(eddy_like_q(ids, N))
+    eng.set_q(eddy_like_q(np.arange(first, first + B), N))
     step_kw = dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024,
-                   member_offset=rank * B)                           # run_parameterized.py:50
+                   member_offset=first)                              # run_parameterized.py:50; Philox keyed by GLOBAL member id
     loop = OnlineLoop(eng, dt, step_kw, dist, args.backend)
 
     def barrier():
@@ -336,9 +406,12 @@ def main():
             dist.barrier()
 
     loop.run(W)
-    gen.set_option('prof_every', 10)    # HIP events around every 10th launch: each pair idles the GPU for ~12 us
-    gen.profile(1)                      # dominant kernel: conv layer 2 (128->64, 5x5), 75% of the FLOPs
+    stride = prof_stride(K)
+    gen.set_option('prof_every', stride)   # HIP events around every n-th launch: each pair idles the GPU for ~12 us
+    gen.profile(1)                         # dominant kernel: conv layer 2 (128->64, 5x5), 75% of the FLOPs
+    n0 = (loop.nsnap, loop.nstatus)
     elapsed = timed(lambda: loop.run(K), barrier)
+    counted = (loop.nsnap - n0[0], loop.nstatus - n0[1])
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda' if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -347,70 +420,77 @@ def main():
     healthy = bool(np.isfinite(ke).all() and (cfl < 1).all())
 
     out = None
+    kname = ('k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh2<128,64,5x5>') + ' (generator layer 2)'
+    cfg = {'nx': N, 'members_per_gpu': B, 'kind': args.kind}
+    traffic = {'f32': pmc_traffic('pmc_traffic.json', cfg), 'f16x3': pmc_traffic('pmc_traffic_f16x3.json', cfg)}[args.precision]
+    gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
     if rank == 0:
-        total_members = B * world
         value = total_members * K / elapsed
-        cfg = {'nx': N, 'members_per_gpu': B, 'kind': args.kind}
-        traffic = {'f32': pmc_traffic('pmc_traffic.json', cfg), 'f16x3': pmc_traffic('pmc_traffic_f16x3.json', cfg)}[args.precision]
-        kname = ('k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh2<128,64,5x5>') + ' (generator layer 2)'
-        roof = mfma_roofline(gen, args.precision, N, B, kname, traffic)
-        gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
+        roof = mfma_roofline(gen, args.precision, N, B, kname, traffic, stride)
         roof['whole_step_generator_tflops'] = gen_flop_per_member_step * value / world / 1e12
         dtype = {'f32': 'f64 spectral core + f32 generator (exact-f32 MFMA)',
                  'f16x3': 'f64 spectral core + f32-class generator: f16 hi/lo split operands, 3 f16 MFMAs per '
                           'product, f32 accumulate (error vs a float64 ground truth <= the exact-f32 path, '
                           'tests/test_gpu_precision.py)'}[args.precision]
+        shard = (f'ONE {total_members}-member ensemble split over {world} GPU(s): {B} members on rank 0' if strong else
+                 f'{B} members per GPU (BASELINE configs[2] shard: 1024 members / 8 GPUs)')
         out = {
             'metric': 'ensemble-timesteps/sec, 64^2 2-layer eddy + GAN param',
             'value': value, 'unit': 'ensemble-timesteps/sec', 'n_gpus': world, 'steps': K, 'warmup': W,
-            'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * elapsed / K, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': dtype,
             'data': f'synthetic band-limited PV fields (seeded per member); generator weights: {wsrc}',
-            'config': {'workload': f'eddy {N}x{N} 2-layer + {args.kind.upper()} parameterization, '
-                                   f'{B} members per GPU (BASELINE configs[2] shard: 1024 members / 8 GPUs), '
+            'config': {'workload': f'eddy {N}x{N} 2-layer + {args.kind.upper()} parameterization, {shard}, '
                                    f"sampling='constant' nsteps=1, dt={dt:.0f}s",
                        'members_per_gpu': B, 'total_members': total_members, 'nx': N,
                        'generator_precision': args.precision,
                        'cadence': {'diagnostics_every': int(math.ceil(86400. / dt)), 'snapshot_every': loop.snap_every,
-                                   'status_every': loop.status_every, 'snapshots_in_timed_region': None,
-                                   'status_checks_in_timed_region': None,
+                                   'status_every': loop.status_every, 'snapshots_in_timed_region': counted[0],
+                                   'status_checks_in_timed_region': counted[1],
                                    'ensemble_mean_spectrum': 'one all-reduce of (2,N,N/2+1) f64 per snapshot'},
                        'parallelism': f'ensemble-sharded x{world}, no data-path collective'},
             'roofline': roof,
             'healthy': healthy,
         }
 
-    aux = world == 1 and not args.no_aux
+    aux = world == 1 and not args.no_aux and not strong
+    if aux:
+        # SURVEY §8(d)'s protocol whatever --steps was: 100 warm-up + 2,000 timed steps of the SAME engine, 8 snapshots
+        # and 2 status checks inside, HIP events around every 10th launch of the roofline kernel (200 launches)
+        KS, WS = 2000, 100
+        loop.run(WS)
+        gen.set_option('prof_every', 10)
+        gen.profile(1)
+        n0 = (loop.nsnap, loop.nstatus)
+        els = timed(lambda: loop.run(KS))
+        rs = mfma_roofline(gen, args.precision, N, B, kname, traffic, 10)
+        vs = B * KS / els
+        rs['whole_step_generator_tflops'] = gen_flop_per_member_step * vs / 1e12
+        out['steady'] = {'protocol': 'SURVEY 8(d): 100 warm-up + 2000 timed steps at the reference cadences, independent of --steps',
+                         'value': vs, 'unit': 'ensemble-timesteps/sec', 'steps': KS, 'warmup': WS,
+                         'ms_per_step': 1e3 * els / KS, 'snapshots_in_timed_region': loop.nsnap - n0[0],
+                         'status_checks_in_timed_region': loop.nstatus - n0[1],
+                         'diagnostic_increments_in_timed_region': KS // int(math.ceil(86400. / dt)), 'roofline': rs}
     # the same workload on the exact-f32 matrix cores (auxiliary: same-precision-as-the-reference number)
     if aux and args.precision != 'f32':
-        K32 = min(K, 200)
+        K32 = 200
         gen.set_option('precision', 0)
         loop.run(5)
+        gen.set_option('prof_every', 5)
         gen.profile(1)
         el32 = timed(lambda: loop.run(K32))
         r32 = mfma_roofline(gen, 'f32', N, B, 'k_conv<128,64,5x5> (generator layer 2)',
-                            pmc_traffic('pmc_traffic.json', {'nx': N, 'members_per_gpu': B, 'kind': args.kind}))
+                            pmc_traffic('pmc_traffic.json', {'nx': N, 'members_per_gpu': B, 'kind': args.kind}), 5)
         gen.set_option('precision', PRECISIONS[args.precision])
         out['exact_f32'] = {'value': B * K32 / el32, 'unit': 'ensemble-timesteps/sec', 'steps': K32,
                             'ms_per_step': 1e3 * el32 / K32, 'roofline': r32}
-    if rank == 0:
-        # counted over warm-up + timed (+ the f32 leg); the timed region's share follows from the cadences
-        out['config']['cadence']['snapshots_in_timed_region'] = (W + K) // loop.snap_every - W // loop.snap_every
-        out['config']['cadence']['status_checks_in_timed_region'] = (W + K) // 1000 - W // 1000
+    eng.close()
 
-    # configs[1]: the single-member, launch-latency-bound case
     if aux:
-        K1 = min(4 * K, 2000)
-        e1 = qa.EnsembleEngine(nx=N, n_members=1, device=local_rank, dt=dt)
-        e1.set_q(eddy_like_q([0], N))
-        l1 = OnlineLoop(e1, dt, dict(step_kw, member_offset=0))
-        l1.run(W)
-        el1 = timed(lambda: l1.run(K1))
-        out['b1'] = {'workload': 'BASELINE configs[1]: 64x64 eddy + CGAN, 1 member on 1 GPU (launch-latency-bound)',
-                     'value': K1 / el1, 'unit': 'ensemble-timesteps/sec', 'steps': K1, 'ms_per_step': 1e3 * el1 / K1}
-        e1.close()
-        out['config3'] = leg_config3(qa, local_rank, min(K, 200), min(W, 10))
-        out['config4'] = leg_config4(qa, local_rank, min(K, 100), min(W, 5))
+        out['b1'] = leg_members(qa, local_rank, gen, 1, 2000, 100, 'b1', B1)           # configs[1]
+        out['b1024'] = leg_members(qa, local_rank, gen, 1024, 250, 10, 'b1024', B1024)  # configs[2] whole
+        out['config3'] = leg_config3(qa, local_rank)
+        out['config4'] = leg_config4(qa, local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(N, args.kind, dt)

@@ -10,8 +10,8 @@ B = 8
 q0 = bench.eddy_like_q(list(range(B)), 256)
 res = []
 for team in (True, False):
-    if not team: os.environ['QGX_LARGE_NO_TEAM'] = '1'
     e = qa.EnsembleEngine(nx=256, n_members=B, device=0, dt=3600.)
+    if not team: e.set_option('team', 0)
     e.set_q(q0)
     e.step(int(sys.argv[1]) if len(sys.argv) > 1 else 2, refresh_diag=False)
     res.append({f: e.get(f).cpu().numpy() for f in (L.F_QH, L.F_DQHDT)})

@@ -47,7 +47,8 @@ typedef struct qgx_config {
     int32_t nx;          /* N = nx = ny; even, N = 2^a 3^b, 8 <= N <= 512             */
     int32_t n_members;   /* B: ensemble members resident on this device               */
     int32_t device;      /* HIP device ordinal                                        */
-    int32_t reserved;
+    int32_t plan_only;   /* != 0: the handle is an FFT plan of its grid for qgx_rfft2 / qgx_irfft2 only: tables and
+                            work space, NO model state (every state entry point returns QGX_ERR_STATE)              */
     double  L;           /* domain size [m]                     (pyqg default 1e6)     */
     double  dt;          /* time step [s]                       (7200)                */
     double  rek;         /* bottom drag [1/s]                   (5.787e-7)            */
@@ -137,6 +138,13 @@ int64_t qgx_step_count(const qgx_model *m);
  * (or a run raised a flag), 0 before the first unparameterized step or on other grids */
 int qgx_run_kernel_state(const qgx_model *m);
 int qgx_reset_time(qgx_model *m);
+/* Kernel-path switches of a model (no reference counterpart; cross-checks in tests/, A/B timing in bench_tools/):
+ * every setting computes the same step, only the fusion / tiling differs.  "genfuse" (0|1: generator output and
+ * next-input kernels folded into the small-grid step kernel), "diag_fused" (0|1: one-kernel diagnostics increment),
+ * "lsplit" (-1 auto|0|1: one workgroup per member and layer), "spec_threads" (0 auto|256|512|1024), "team" (0|1:
+ * XCD-resident runs at 256 x 256), "team_min" (shortest such run), "large_fused", "large_lazy_q",
+ * "large_specialised" (0|1: the large-grid kernel variants).  The library reads NO environment variable. */
+int qgx_set_option(qgx_model *m, const char *name, int value);
 
 /* status reductions of pyqg's _print_status: out_dev[2*b+0] = KE, [2*b+1] = CFL (of ph,u,v as the last step stored
  * them; after steps with refresh_diag == 0 the current state is inverted first) */
@@ -156,7 +164,15 @@ enum qgx_diag {              /* per member; pyqg normalisation 1/M^2 */
     QGX_D_KEFRICTIONSPEC = 6,
     QGX_D_PARAMSPEC = 7,
     QGX_D_PARAMSPEC_APEFLUX = 8,   /* the APE and KE parts of paramspec (comparison_tools.py:174-176) */
-    QGX_D_PARAMSPEC_KEFLUX = 9
+    QGX_D_PARAMSPEC_KEFLUX = 9,
+    /* (B,N,N/2+1) each: the filter's dissipation of energy / barotropic enstrophy and the barotropic-enstrophy budget
+     * (flux, generation, bottom friction, parameterization) — the remaining keys of comparison_tools.py:222-225,365-368 */
+    QGX_D_DISSSPEC = 10,
+    QGX_D_ENSDISSSPEC = 11,
+    QGX_D_ENSFLUX = 12,
+    QGX_D_ENSGENSPEC = 13,
+    QGX_D_ENSFRICTIONSPEC = 14,
+    QGX_D_ENSPARAMSPEC = 15
 };
 int qgx_diag_config(qgx_model *m, int64_t start_step, int every);   /* every <= 0 disables */
 int qgx_diag_get(qgx_model *m, int diag, double *out_dev, void *stream);   /* time mean */

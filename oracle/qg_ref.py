@@ -281,6 +281,18 @@ class QGModelRef:
             1j * self.k * (self.del1 * self.ph[0] + self.del2 * self.ph[1])
             * np.conj(self.ph[0] - self.ph[1])) / M2
         d['KEfrictionspec'] = -self.rek * self.del2 * self.wv2 * np.abs(self.ph[1]) ** 2 / M2
+        # ---- the barotropic-enstrophy budget and the filter's dissipation (pyqg model.py::_initialize_core_diagnostics:
+        # Dissspec, ENSDissspec, ENSfrictionspec, ENSparamspec; qg_model.py::_initialize_model_diagnostics: ENSflux,
+        # ENSgenspec — the remaining keys the reference reads, comparison_tools.py:222-225).  Each is
+        # Re[sum_k Hk/H conj(qh_k) X_k] / M^2 for one term X_k of the PV tendency (energy: -conj(ph_k) in place of conj(qh_k)).
+        hr = (self.Hi / self.H)[:, None, None]
+        Jq = self._advect_h(self.q, self.u, self.v)           # model.py::_advect with the perturbation velocities
+        d['ENSflux'] = -(hr * np.real(np.conj(self.qh) * Jq)).sum(axis=0) / M2
+        d['ENSgenspec'] = -(hr * np.real(np.conj(self.qh) * self._ikQy[:, None, :] * self.ph)).sum(axis=0) / M2
+        d['ENSfrictionspec'] = self.rek * self.Hi[-1] / self.H * self.wv2 * np.real(np.conj(self.qh[-1]) * self.ph[-1]) / M2
+        diss = self._dissipation_spectrum()
+        d['Dissspec'] = -(hr * np.real(np.conj(self.ph) * diss)).sum(axis=0) / self.dt / M2
+        d['ENSDissspec'] = (hr * np.real(np.conj(self.qh) * diss)).sum(axis=0) / self.dt / M2
         d['EKE'] = 0.5 * (self.v ** 2).mean(axis=(-1, -2))
         d['EKEdiss'] = self.Hi[-1] / self.H * self.rek * (self.v[-1] ** 2 + self.u[-1] ** 2).mean()
         if self.q_parameterization is not None and hasattr(self, 'dqh'):
@@ -294,7 +306,20 @@ class QGModelRef:
                 (self.ph[0] - self.ph[1]) * np.conj(dph[0] - dph[1])) / M2
             d['paramspec_KEflux'] = self.wv2 * np.real(self.del1 * self.ph[0] * np.conj(dph[0])
                                                        + self.del2 * self.ph[1] * np.conj(dph[1])) / M2
+            d['ENSparamspec'] = (hr * np.real(np.conj(self.qh) * self.dqh)).sum(axis=0) / M2
         return d
+
+    def _dissipation_spectrum(self):
+        """model.py::_initialize_core_diagnostics::dissipation_spectrum: what the exponential filter removes from the
+        AB update the coming _forward_timestep will make, (filtr - 1) (qh + dt1 dqhdt + dt2 dqhdt_p + dt3 dqhdt_pp), with
+        the coefficients of the CURRENT ablevel (diagnostics are evaluated before the time step)."""
+        if self.ablevel == 0:
+            dt1, dt2, dt3 = self.dt, 0.0, 0.0
+        elif self.ablevel == 1:
+            dt1, dt2, dt3 = 1.5 * self.dt, -0.5 * self.dt, 0.0
+        else:
+            dt1, dt2, dt3 = 23. / 12. * self.dt, -16. / 12. * self.dt, 5. / 12. * self.dt
+        return (self.filtr - 1.0) * (self.qh + dt1 * self.dqhdt + dt2 * self.dqhdt_p + dt3 * self.dqhdt_pp)
 
     def _advect_h(self, q, u, v):
         """-> spectral J(psi, q) in flux form (model.py::_advect)."""

@@ -16,7 +16,7 @@ class QgxError(RuntimeError):
 
 class qgx_config(C.Structure):
     _fields_ = [('nx', C.c_int32), ('n_members', C.c_int32), ('device', C.c_int32),
-                ('reserved', C.c_int32),
+                ('plan_only', C.c_int32),
                 ('L', C.c_double), ('dt', C.c_double), ('rek', C.c_double), ('delta', C.c_double),
                 ('beta', C.c_double), ('rd', C.c_double), ('U1', C.c_double), ('U2', C.c_double),
                 ('H1', C.c_double), ('filterfac', C.c_double)]
@@ -42,7 +42,8 @@ F_Q, F_QH, F_PH, F_U, F_V, F_DQHDT, F_DQHDT_P, F_DQHDT_PP, F_S, F_Z, F_P = range
 T_FILTR, T_WV2, T_A, T_KK, T_LL = range(5)
 SAMPLING_AR1, SAMPLING_CONSTANT = 0, 1
 DIAGS = ['KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec', 'paramspec',
-         'paramspec_APEflux', 'paramspec_KEflux']
+         'paramspec_APEflux', 'paramspec_KEflux', 'Dissspec', 'ENSDissspec', 'ENSflux', 'ENSgenspec', 'ENSfrictionspec',
+         'ENSparamspec']
 GEN_GAN, GEN_VAE, GEN_GZ = 0, 1, 2
 
 # every symbol include/qgx.h declares: (name, restype, argtypes)
@@ -59,6 +60,7 @@ SYMBOLS = [
     ('qgx_step_count', C.c_int64, [C.c_void_p]),
     ('qgx_run_kernel_state', C.c_int, [C.c_void_p]),
     ('qgx_reset_time', C.c_int, [C.c_void_p]),
+    ('qgx_set_option', C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ('qgx_status_ke_cfl', C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ('qgx_diag_config', C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     ('qgx_diag_get', C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

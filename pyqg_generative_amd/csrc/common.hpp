@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <string>
 #include "../../include/qgx.h"
@@ -31,7 +32,43 @@ void set_error(const char *fmt, ...);
         }                                                                          \
     } while (0)
 
+// entry points that touch the model state refuse a plan-only handle (qgx_config::plan_only)
+#define QGX_NEEDS_STATE(m, what)                                                            \
+    do {                                                                                   \
+        if ((m) && (m)->plan_only) {                                                       \
+            qgx::set_error("%s: the handle is an FFT plan only (created with plan_only), it has no model state", what); \
+            return QGX_ERR_STATE;                                                          \
+        }                                                                                  \
+    } while (0)
+
 constexpr int MAX_RADIX_PASSES = 12;
+
+// Kernel-path switches of a model (qgx_set_option).  They select between equivalent kernels of the product library
+// (cross-checks in tests/, A/B timing in bench_tools/); none changes what is computed beyond rounding order.
+struct ModelOpts {
+    int genfuse = 1;             // small grids: generator output / next-input kernels folded into the step kernel
+    int diag_fused = 1;          // small grids: one-kernel diagnostics increment (0: the nine launches of diag.hip)
+    int lsplit = -1;             // small grids: two workgroups per member, one per layer (-1 auto | 0 | 1)
+    int spec_threads = 0;        // small grids: threads of the one-workgroup-per-member kernels (0 auto | 256 | 512 | 1024)
+    int team = 1;                // 256 x 256: XCD-resident runs of unparameterized steps
+    int team_min = 2;            //   shortest run handed to that kernel
+    int team_fault = 0;          //   A/B library only: raise the run kernel's flag at the end of the next run (test hook)
+    int large_fused = 1;         // large grids: fused row / column kernels (0: one launch per pass and pointwise phase)
+    int large_lazy_q = 1;        // large grids: unparameterized steps keep no real-space q
+    int large_specialised = 1;   // large grids: compile-time-N kernels at 128 / 256 / 512
+};
+
+// Tile-shape tuning aids read from the environment exist in the A/B library only (make ab); the product library
+// always runs the measured defaults, so no environment variable can alter a production run.
+static inline int tune_env(const char *name, int dflt) {
+#ifdef QGX_AB
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // Device-visible description of one model's grid and constants (passed by value).
 struct SpecDev {
@@ -82,9 +119,12 @@ struct StepArgs {
 };
 
 // time-averaged diagnostics (diag.hip; the small-grid increment is one kernel of spectral_small.hip)
-struct DiagConst { double del1, del2, rdm2, Udiff, rek, invM2, H0, H1; };
+struct DiagConst { double del1, del2, rdm2, Udiff, rek, invM2, H0, H1;
+                   double dt1, dt2, dt3, invdt; };       // AB coefficients of the step about to be taken (Dissspec)
 struct DiagAcc { double *KEspec, *Ensspec, *entspec, *APEflux, *KEflux, *APEgenspec, *KEfrictionspec, *paramspec,
-                        *paramspec_APEflux, *paramspec_KEflux; };
+                        *paramspec_APEflux, *paramspec_KEflux,
+                        *Dissspec, *ENSDissspec, *ENSflux, *ENSgenspec, *ENSfrictionspec, *ENSparamspec; };
+constexpr int N_DIAGS = 16;
 
 }  // namespace qgx
 
@@ -93,8 +133,10 @@ struct qgx_generator;
 struct qgx_model {
     qgx_config cfg;
     qgx::SpecDev d;
+    qgx::ModelOpts opts;
     int N, NK, B;
     bool small;                     // whole member field fits one CU's LDS
+    bool plan_only = false;         // FFT plan of the grid only: tables + work space, no model state (qgx_config::plan_only)
     // tables (device) + host copies for qgx_get_table
     double *t_filtr = nullptr, *t_wv2 = nullptr, *t_a = nullptr, *t_kk = nullptr, *t_ll = nullptr;
     double2 *t_tw = nullptr;
@@ -104,15 +146,24 @@ struct qgx_model {
     double *q = nullptr, *u = nullptr, *v = nullptr, *S = nullptr;
     double2 *qh[2] = {nullptr, nullptr};   // ping-pong; qh[cur_q] is current
     double2 *ph = nullptr, *dqh = nullptr; // dqh: spectral forcing of the last step (pyqg m.dqh)
-    double2 *dq[3] = {nullptr, nullptr, nullptr};
+    double2 *dq[4] = {nullptr, nullptr, nullptr, nullptr};   // AB3 tendency history; [3]: large grids, spare slot of the run kernel
     double2 *zbuf = nullptr;               // large-N path: (B,3,N,N) complex work array
     bool q_stale = false;                  // large-N path: q lags qh (unparameterized steps keep no real-space q)
     bool uv_stale = false;                 // the last step did not store ph, u, v (refresh_diag == 0): status inverts first
     void *team_ctl = nullptr;              // large-N path: census / barrier block of the XCD-resident step kernel
     int team_state = 0;                    //   0 not probed, 1 available, -1 not available
     bool team_pending = false;             //   a run was launched whose flags have not been read back yet
+    struct TeamUndo {                      //   bookkeeping as it was before the pending run (a run writes ONLY to buffers
+        int K = 0;                         //   that hold nothing live, so a run that raised a flag is undone by restoring
+        int cur_q, i_new, i_p, i_pp, i_x;  //   these and replayed on the three-launch path)
+        int64_t tc;
+        int ablevel;
+        bool uv_stale, q_stale;
+    } team_undo;
+    hipStream_t team_stream = nullptr;     //   the stream the pending run was launched on (its flag is read back there)
+    int team_replays = 0;                  //   runs that raised a flag and were replayed
     int cur_q = 0;
-    int i_new = 0, i_p = 1, i_pp = 2;      // roles of dq[]
+    int i_new = 0, i_p = 1, i_pp = 2, i_x = 3;   // roles of dq[]
     void *z = nullptr;                     // latent noise (B,2,N,N) float or double
     void *xi = nullptr;                    // scratch white noise for AR1
     bool z_double = false;
@@ -127,9 +178,9 @@ struct qgx_model {
     // time-averaged diagnostics (diag.hip)
     int64_t dg_start = 0, dg_count = 0;
     int dg_every = 0;
-    double *dg_R[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    double *dg_S[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    double *dg_acc[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *dg_R[7] = {};
+    double *dg_S[7] = {};
+    double *dg_acc[qgx::N_DIAGS] = {};
 };
 
 namespace qgx {
@@ -146,7 +197,15 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
                       int demean, hipStream_t st, const NoiseUpdate *nu, GenFuse *defer = nullptr, bool input_ready = false);
 // the generator's input buffer, input scales and range words for the GenFuse::X part (after reserve)
 int generator_input_info(qgx_generator *g, int B, int N, GenFuse *gf);
-bool small_layer_split(const SpecDev &d);
+bool small_layer_split(const SpecDev &d, const ModelOpts &o);
+// spectral_small.hip
+bool small_path_fits(int N);
+int small_prepare(const SpecDev &d);
+int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStream_t st);
+int small_q_to_qh(const SpecDev &d, const ModelOpts &o, const double *q, double2 *qh, hipStream_t st);
+int small_qh_to_q(const SpecDev &d, const ModelOpts &o, const double2 *qh, double *q, hipStream_t st);
+int small_invert(const SpecDev &d, const ModelOpts &o, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st);
+
 bool generator_noise_is_double(const qgx_generator *g);
 int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st);
 int noise_update(void *z, const void *xi_ext, bool is_double, int B, int n_per_member, uint64_t seed,

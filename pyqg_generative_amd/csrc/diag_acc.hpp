@@ -1,5 +1,5 @@
 // One spectral element of model.py::_increment_diagnostics (shared by diag.hip::k_diag_accumulate and
-// spectral_small.hip::k_diag_small): the ten time-averaged diagnostics, pyqg's 1/M^2 normalisation.
+// spectral_small.hip::k_diag_small): the sixteen time-averaged diagnostics, pyqg's 1/M^2 normalisation.
 #pragma once
 #include "common.hpp"
 
@@ -8,7 +8,8 @@ namespace qgx {
 __device__ __forceinline__ void diag_accumulate_elem(const SpecDev &d, const DiagConst &c, const DiagAcc &a, int idx, int i, int j,
                                                      size_t o, size_t o2, int sz, double2 q1, double2 q2, double2 p1, double2 p2,
                                                      double2 A3, double2 B3, double2 A4, double2 B4, double2 A5, double2 B5,
-                                                     bool has_S, double2 s1, double2 s2) {
+                                                     bool has_S, double2 s1, double2 s2, double2 A6, double2 B6, double2 A7,
+                                                     double2 B7, double2 hp1, double2 hp2, double2 hpp1, double2 hpp2) {
     const double kx = d.kk[i], ly = d.ll[j], wv2 = d.wv2[idx];
     a.KEspec[o] += wv2 * (p1.x * p1.x + p1.y * p1.y) * c.invM2;
     a.KEspec[o + sz] += wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
@@ -41,7 +42,30 @@ __device__ __forceinline__ void diag_accumulate_elem(const SpecDev &d, const Dia
         const double d2x = a10 * s1.x + a11 * s2.x, d2y = a10 * s1.y + a11 * s2.y;
         a.paramspec_APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * (d1x - d2x) + dpy * (d1y - d2y)) * c.invM2;
         a.paramspec_KEflux[o2] += wv2 * (c.del1 * (p1.x * d1x + p1.y * d1y) + c.del2 * (p2.x * d2x + p2.y * d2y)) * c.invM2;
+        // ENSparamspec = Re[ sum_k Hk/H conj(qh_k) dqh_k ]
+        a.ENSparamspec[o2] += (c.H0 * (q1.x * s1.x + q1.y * s1.y) + c.H1 * (q2.x * s2.x + q2.y * s2.y)) * c.invM2;
     }
+    // ---- the barotropic-enstrophy budget and the filter's dissipation (pyqg model.py::_initialize_core_diagnostics,
+    // qg_model.py::_initialize_model_diagnostics): every term is Re[sum_k Hk/H conj(qh_k) X_k] / M^2 for one term X_k of
+    // the PV tendency, so that they close the budget of sum_k Hk/H |qh_k|^2 / 2 wavenumber by wavenumber.
+    // Jq_k = ik A + il B, (A, B) = transforms of (u_k q_k, v_k q_k) with the PERTURBATION velocities (model.py::_advect)
+    const double g1x = -(kx * A6.y + ly * B6.y), g1y = (kx * A6.x + ly * B6.x);
+    const double g2x = -(kx * A7.y + ly * B7.y), g2y = (kx * A7.x + ly * B7.x);
+    a.ENSflux[o2] += -(c.H0 * (q1.x * g1x + q1.y * g1y) + c.H1 * (q2.x * g2x + q2.y * g2y)) * c.invM2;
+    // -Re[conj(qh_k) ik Qy_k ph_k] = -k Qy_k (q.y p.x - q.x p.y)
+    a.ENSgenspec[o2] += -kx * (c.H0 * d.Qy[0] * (q1.y * p1.x - q1.x * p1.y) + c.H1 * d.Qy[1] * (q2.y * p2.x - q2.x * p2.y)) * c.invM2;
+    a.ENSfrictionspec[o2] += c.rek * c.H1 * wv2 * (q2.x * p2.x + q2.y * p2.y) * c.invM2;
+    // the tendency the step is about to use: T_k = -(Jq_k + ik U_k qh_k) - ik Qy_k ph_k [+ rek wv2 ph_2] [+ dqh_k], and what
+    // the exponential filter removes from the unfiltered AB update: diss_k = (filtr - 1) (qh_k + dt1 T_k + dt2 T'_k + dt3 T''_k)
+    double t1x = -(g1x - kx * d.U[0] * q1.y) + kx * d.Qy[0] * p1.y, t1y = -(g1y + kx * d.U[0] * q1.x) - kx * d.Qy[0] * p1.x;
+    double t2x = -(g2x - kx * d.U[1] * q2.y) + kx * d.Qy[1] * p2.y, t2y = -(g2y + kx * d.U[1] * q2.x) - kx * d.Qy[1] * p2.x;
+    if (c.rek != 0.0) { t2x += c.rek * wv2 * p2.x; t2y += c.rek * wv2 * p2.y; }
+    if (has_S) { t1x += s1.x; t1y += s1.y; t2x += s2.x; t2y += s2.y; }
+    const double fm1 = d.filtr[idx] - 1.0;
+    const double e1x = fm1 * (q1.x + c.dt1 * t1x + c.dt2 * hp1.x + c.dt3 * hpp1.x), e1y = fm1 * (q1.y + c.dt1 * t1y + c.dt2 * hp1.y + c.dt3 * hpp1.y);
+    const double e2x = fm1 * (q2.x + c.dt1 * t2x + c.dt2 * hp2.x + c.dt3 * hpp2.x), e2y = fm1 * (q2.y + c.dt1 * t2y + c.dt2 * hp2.y + c.dt3 * hpp2.y);
+    a.Dissspec[o2] += -(c.H0 * (p1.x * e1x + p1.y * e1y) + c.H1 * (p2.x * e2x + p2.y * e2y)) * c.invdt * c.invM2;
+    a.ENSDissspec[o2] += (c.H0 * (q1.x * e1x + q1.y * e1y) + c.H1 * (q2.x * e2x + q2.y * e2y)) * c.invdt * c.invM2;
 }
 
 }  // namespace qgx

@@ -18,13 +18,6 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-// spectral_small.hip
-bool small_path_fits(int N);
-int small_prepare(const SpecDev &d);
-int small_step(const SpecDev &d, const StepArgs &a, hipStream_t st);
-int small_q_to_qh(const SpecDev &d, const double *q, double2 *qh, hipStream_t st);
-int small_qh_to_q(const SpecDev &d, const double2 *qh, double *q, hipStream_t st);
-int small_invert(const SpecDev &d, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st);
 // spectral_large.hip
 int large_prepare(const SpecDev &d);
 int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st);
@@ -34,7 +27,7 @@ int large_step(qgx_model *m, const StepArgs &a, hipStream_t st);
 int large_ensure_q(qgx_model *m, hipStream_t st);
 int large_zpad();
 int large_team_available(qgx_model *m, hipStream_t st);
-int large_team_check(qgx_model *m, hipStream_t st);
+int large_team_check(qgx_model *m, hipStream_t st, unsigned *flag);
 int large_team_steps(qgx_model *m, int K, int ablevel0, const double coef[3][3], const double2 *qh_src, double2 *qh_dst,
                      const double2 *p_src, const double2 *pp_src, double2 *p_dst, double2 *pp_dst, hipStream_t st);
 
@@ -59,7 +52,7 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
     a.ph = m->ph; a.u = m->u; a.v = m->v;
     a.weight = weight;
     a.has_S = has_S ? 1 : 0; a.demean = demean; a.diag = diag;
-    int rc = m->small ? small_step(m->d, a, st) : large_step(m, a, st);
+    int rc = m->small ? small_step(m->d, m->opts, a, st) : large_step(m, a, st);
     if (rc) return rc;
     const int dead = m->i_pp;
     m->i_pp = m->i_p; m->i_p = m->i_new; m->i_new = dead;
@@ -70,21 +63,48 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
 }
 
 // K unparameterized steps without diagnostics output in one launch of the XCD-resident kernel (spectral_large.hip):
-// the same AB3 schedule and history rotation as K calls of model_step_once.
+// the same AB3 schedule and history rotation as K calls of model_step_once.  The run is a TRANSACTION: it reads the
+// live buffers (qh[cur], dq[i_new], dq[i_p]) and writes only buffers that hold nothing live (qh[cur ^ 1], dq[i_pp],
+// dq[i_x]), and the bookkeeping before it is kept in team_undo until its flag word has been read back (team_settle).
 static int model_step_run(qgx_model *m, int K, hipStream_t st) {
     const double dt = m->cfg.dt;
     const double coef[3][3] = {{dt, 0.0, 0.0}, {1.5 * dt, -0.5 * dt, 0.0}, {23. / 12. * dt, -16. / 12. * dt, 5. / 12. * dt}};
-    int in = m->i_new, ip = m->i_p, ipp = m->i_pp;
-    for (int s = 0; s < K; ++s) { const int dead = ipp; ipp = ip; ip = in; in = dead; }
-    // before: i_new = T_{n-1}, i_p = T_{n-2}; after: the new i_new holds T_{n+K-1}, the new i_p holds T_{n+K-2}
-    int rc = large_team_steps(m, K, m->ablevel, coef, m->qh[m->cur_q], m->qh[m->cur_q ^ (K & 1)], m->dq[m->i_new],
-                              m->dq[m->i_p], m->dq[in], m->dq[ip], st);
-    if (rc) return rc;
-    m->i_new = in; m->i_p = ip; m->i_pp = ipp;
-    m->cur_q ^= (K & 1);
+    qgx_model::TeamUndo &u = m->team_undo;
+    u.K = K; u.cur_q = m->cur_q; u.i_new = m->i_new; u.i_p = m->i_p; u.i_pp = m->i_pp; u.i_x = m->i_x;
+    u.tc = m->tc; u.ablevel = m->ablevel; u.uv_stale = m->uv_stale; u.q_stale = m->q_stale;
+    // before: i_new = T_{n-1}, i_p = T_{n-2}; after: T_{n+K-1} in the old i_pp, T_{n+K-2} in the old spare slot
+    int rc = large_team_steps(m, K, m->ablevel, coef, m->qh[m->cur_q], m->qh[m->cur_q ^ 1], m->dq[m->i_new],
+                              m->dq[m->i_p], m->dq[m->i_pp], m->dq[m->i_x], st);
+    if (rc) { u.K = 0; return rc; }
+    m->i_new = u.i_pp; m->i_p = u.i_x; m->i_pp = u.i_new; m->i_x = u.i_p;
+    m->cur_q ^= 1;
     m->tc += K;
     m->ablevel = m->ablevel + K > 2 ? 2 : m->ablevel + K;
     m->uv_stale = true;
+    return QGX_OK;
+}
+
+// Settles the pending run of the XCD-resident kernel, if any (one stream synchronisation).  A run that raised a flag
+// (its bounded waits timed out because other work held CUs, or its workgroups were not co-resident) left its inputs
+// intact: the bookkeeping is restored, the kernel is switched off for this model and the K steps are replayed on the
+// three-launch path — a long run degrades, it is not lost.  qgx_run_kernel_state() reports -1 afterwards.
+static int team_settle(qgx_model *m, hipStream_t st) {
+    if (!m || m->small || !m->team_pending) return QGX_OK;
+    unsigned flag = 0;
+    (void)st;
+    st = m->team_stream;                 // the run's own stream: the read-back and the replay are ordered behind it
+    int rc = large_team_check(m, st, &flag);
+    if (rc) return rc;
+    const qgx_model::TeamUndo u = m->team_undo;
+    m->team_undo.K = 0;
+    if (flag == 0) return QGX_OK;
+    m->team_state = -1;
+    m->team_replays += 1;
+    QGX_REQUIRE(u.K > 0, "XCD-resident step kernel raised flag %u and left no undo record: the model state is undefined", flag);
+    m->cur_q = u.cur_q; m->i_new = u.i_new; m->i_p = u.i_p; m->i_pp = u.i_pp; m->i_x = u.i_x;
+    m->tc = u.tc; m->ablevel = u.ablevel; m->uv_stale = u.uv_stale; m->q_stale = u.q_stale;
+    for (int s = 0; s < u.K; ++s)
+        if ((rc = model_step_once(m, false, nullptr, 1.0, 0, 0, st))) return rc;
     return QGX_OK;
 }
 
@@ -248,14 +268,16 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
     d.H[0] = cfg->H1; d.H[1] = cfg->H1 / cfg->delta; d.Htot = d.H[0] + d.H[1];
 
     const size_t nr = (size_t)B * 2 * N * N, ns = (size_t)B * 2 * N * NK;
-    if ((rc = dalloc(m->q, nr)) || (rc = dalloc(m->u, nr)) || (rc = dalloc(m->v, nr)) ||
+    m->plan_only = cfg->plan_only != 0;
+    if (m->plan_only) { /* transforms only: no state */ }
+    else if ((rc = dalloc(m->q, nr)) || (rc = dalloc(m->u, nr)) || (rc = dalloc(m->v, nr)) ||
         (rc = dalloc(m->S, nr)) || (rc = dalloc(m->qh[0], ns)) || (rc = dalloc(m->qh[1], ns)) ||
         (rc = dalloc(m->ph, ns)) || (rc = dalloc(m->dqh, ns)) || (rc = dalloc(m->dq[0], ns)) ||
-        (rc = dalloc(m->dq[1], ns)) || (rc = dalloc(m->dq[2], ns))) {
+        (rc = dalloc(m->dq[1], ns)) || (rc = dalloc(m->dq[2], ns)) || (N == 256 && (rc = dalloc(m->dq[3], ns)))) {
         qgx_destroy(m);
         return rc;
     }
-    {   // latent noise + scratch sized for the wider (double) case
+    if (!m->plan_only) {   // latent noise + scratch sized for the wider (double) case
         void *p = nullptr, *p2 = nullptr;
         if (hipMalloc(&p, nr * sizeof(double)) != hipSuccess || hipMalloc(&p2, nr * sizeof(double)) != hipSuccess) {
             set_error("hipMalloc of noise buffers failed");
@@ -281,7 +303,7 @@ extern "C" int qgx_destroy(qgx_model *m) {
     if (!m) return QGX_OK;
     (void)hipSetDevice(m->cfg.device);
     void *ptrs[] = {m->t_filtr, m->t_wv2, m->t_a, m->t_kk, m->t_ll, m->t_tw, m->t_pos, m->q, m->u, m->v,
-                    m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->zbuf, m->team_ctl,
+                    m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->dq[3], m->zbuf, m->team_ctl,
                     m->z, m->xi, m->dg_R[0], m->dg_R[1], m->dg_R[2], m->dg_R[3], m->dg_R[4], m->dg_S[0], m->dg_S[1],
                     m->dg_S[2], m->dg_S[3], m->dg_S[4], m->dg_acc[0], m->dg_acc[1], m->dg_acc[2], m->dg_acc[3],
                     m->dg_acc[4], m->dg_acc[5], m->dg_acc[6], m->dg_acc[7], m->dg_acc[8], m->dg_acc[9]};
@@ -303,10 +325,17 @@ extern "C" size_t qgx_field_bytes(const qgx_model *m, int field) {
 }
 
 extern "C" int qgx_get(qgx_model *m, int field, void *out_dev, void *stream) {
-    if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
+    QGX_NEEDS_STATE(m, "qgx_get");
+    { int trc = team_settle(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m && out_dev, "qgx_get: null argument");
+    if (m->uv_stale && (field == QGX_F_U || field == QGX_F_V || field == QGX_F_PH || field == QGX_F_P)) {
+        // the steps since the last refresh stored no ph, u, v (refresh_diag == 0, every step of a run kernel): hand out
+        // the fields of the CURRENT state rather than those of an older one (as qgx_status_ke_cfl does)
+        int irc = qgx_invert(m, stream);
+        if (irc) return irc;
+    }
     if (field == QGX_F_P)      // pyqg's derived field p = ifft(ph) (model.py::_calc_derived_fields), straight into the caller's buffer
-        return m->small ? small_qh_to_q(m->d, m->ph, (double *)out_dev, (hipStream_t)stream)
+        return m->small ? small_qh_to_q(m->d, m->opts, m->ph, (double *)out_dev, (hipStream_t)stream)
                         : large_qh_to_q(m, m->ph, (double *)out_dev, (hipStream_t)stream);
     if (field == QGX_F_Q && !m->small) { int rc = large_ensure_q(m, (hipStream_t)stream); if (rc) return rc; }
     const void *src = nullptr;
@@ -344,42 +373,77 @@ extern "C" int qgx_get_table(qgx_model *m, int table, double *out) {
 }
 
 extern "C" int qgx_set_q(qgx_model *m, const double *q_dev, void *stream) {
+    QGX_NEEDS_STATE(m, "qgx_set_q");
     QGX_REQUIRE(m && q_dev, "qgx_set_q: null argument");
+    { int trc = team_settle(m, (hipStream_t)stream); if (trc) return trc; }
     hipStream_t st = (hipStream_t)stream;
     QGX_HIP(hipMemcpyAsync(m->q, q_dev, qgx_field_bytes(m, QGX_F_Q), hipMemcpyDeviceToDevice, st));
     m->q_stale = false;
-    return m->small ? small_q_to_qh(m->d, m->q, m->qh[m->cur_q], st) : large_q_to_qh(m, m->q, m->qh[m->cur_q], st);
+    return m->small ? small_q_to_qh(m->d, m->opts, m->q, m->qh[m->cur_q], st) : large_q_to_qh(m, m->q, m->qh[m->cur_q], st);
 }
 
 extern "C" int qgx_set_qh(qgx_model *m, const double *qh_dev, void *stream) {
+    QGX_NEEDS_STATE(m, "qgx_set_qh");
     QGX_REQUIRE(m && qh_dev, "qgx_set_qh: null argument");
+    { int trc = team_settle(m, (hipStream_t)stream); if (trc) return trc; }
     hipStream_t st = (hipStream_t)stream;
     QGX_HIP(hipMemcpyAsync(m->qh[m->cur_q], qh_dev, qgx_field_bytes(m, QGX_F_QH), hipMemcpyDeviceToDevice, st));
     m->q_stale = false;
-    return m->small ? small_qh_to_q(m->d, m->qh[m->cur_q], m->q, st) : large_qh_to_q(m, m->qh[m->cur_q], m->q, st);
+    return m->small ? small_qh_to_q(m->d, m->opts, m->qh[m->cur_q], m->q, st) : large_qh_to_q(m, m->qh[m->cur_q], m->q, st);
 }
 
 extern "C" int qgx_invert(qgx_model *m, void *stream) {
-    if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
+    QGX_NEEDS_STATE(m, "qgx_invert");
+    { int trc = team_settle(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m, "qgx_invert: null model");
     hipStream_t st = (hipStream_t)stream;
     m->uv_stale = false;
-    return m->small ? small_invert(m->d, m->qh[m->cur_q], m->ph, m->u, m->v, st) : large_invert(m, st);
+    return m->small ? small_invert(m->d, m->opts, m->qh[m->cur_q], m->ph, m->u, m->v, st) : large_invert(m, st);
+}
+
+// kernel-path switches (ModelOpts, common.hpp): cross-checks and A/B timing; every combination computes the same step
+extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
+    QGX_REQUIRE(m && name, "qgx_set_option: null argument");
+    ModelOpts &o = m->opts;
+    if (!strcmp(name, "genfuse")) o.genfuse = value ? 1 : 0;
+    else if (!strcmp(name, "diag_fused")) o.diag_fused = value ? 1 : 0;
+    else if (!strcmp(name, "lsplit")) { QGX_REQUIRE(value >= -1 && value <= 1, "lsplit must be -1 (auto), 0 or 1"); o.lsplit = value; }
+    else if (!strcmp(name, "spec_threads")) {
+        QGX_REQUIRE(value == 0 || value == 256 || value == 512 || value == 1024, "spec_threads must be 0 (auto), 256, 512 or 1024");
+        o.spec_threads = value;
+    }
+    else if (!strcmp(name, "team")) o.team = value ? 1 : 0;
+    else if (!strcmp(name, "team_min")) { QGX_REQUIRE(value >= 1, "team_min must be >= 1"); o.team_min = value; }
+    else if (!strcmp(name, "team_fault")) {
+#ifdef QGX_AB
+        o.team_fault = value ? 1 : 0;
+#else
+        QGX_REQUIRE(false, "option 'team_fault' is a test hook of the A/B library only (make ab, QGX_LIB=libqgx_ab.so)");
+#endif
+    }
+    else if (!strcmp(name, "large_fused")) o.large_fused = value ? 1 : 0;
+    else if (!strcmp(name, "large_lazy_q")) o.large_lazy_q = value ? 1 : 0;
+    else if (!strcmp(name, "large_specialised")) o.large_specialised = value ? 1 : 0;
+    else QGX_REQUIRE(false, "unknown model option '%s'", name);
+    return QGX_OK;
 }
 
 extern "C" int64_t qgx_step_count(const qgx_model *m) { return m ? m->tc : -1; }
 extern "C" int qgx_run_kernel_state(const qgx_model *m) { return m ? m->team_state : 0; }
 
 extern "C" int qgx_reset_time(qgx_model *m) {
+    QGX_NEEDS_STATE(m, "qgx_reset_time");
     QGX_REQUIRE(m, "qgx_reset_time: null model");
+    { int trc = team_settle(m, nullptr); if (trc) return trc; }
     m->tc = 0; m->ablevel = 0; m->have_noise = false; m->const_counter = 0; m->have_forcing = false;
     const size_t ns = (size_t)m->B * 2 * m->N * m->NK;
-    for (int i = 0; i < 3; ++i) QGX_HIP(hipMemset(m->dq[i], 0, ns * sizeof(double2)));
+    for (int i = 0; i < 4; ++i) if (m->dq[i]) QGX_HIP(hipMemset(m->dq[i], 0, ns * sizeof(double2)));
     return QGX_OK;
 }
 
 extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
-    if (m && !m->small) { int trc = large_team_check(m, (hipStream_t)stream); if (trc) return trc; }
+    QGX_NEEDS_STATE(m, "qgx_status_ke_cfl");
+    { int trc = team_settle(m, (hipStream_t)stream); if (trc) return trc; }
     QGX_REQUIRE(m && out_dev, "qgx_status_ke_cfl: null argument");
     if (m->uv_stale) {
         // the steps since the last refresh stored no ph, u, v: a status of stale (or never written) fields would be
@@ -395,6 +459,7 @@ extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
 // ---- the stepping loop: pyqg model.py::_step_forward with the plugin call of
 // pyqg_generative/models/parameterization.py:23-34 and samplers of stochastic_pyqg.py:30-72
 extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refresh_diag, void *stream) {
+    QGX_NEEDS_STATE(m, "qgx_step");
     QGX_REQUIRE(m && nsteps >= 0, "qgx_step: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int N = m->N, B = m->B;
@@ -407,11 +472,12 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         QGX_REQUIRE(!(p->z_external_dev && nsteps != 1), "qgx_step: external noise needs nsteps_to_run == 1");
         m->z_double = generator_noise_is_double(p->gen);
     }
-    if (!m->small) { int trc = large_team_check(m, st); if (trc) return trc; }
+    { int trc = team_settle(m, st); if (trc) return trc; }
     const bool plain = !(p && (p->gen || p->forcing_dev));
-    const bool fuse_ok = getenv("QGX_NO_GENFUSE") == nullptr;            // A/B aid (tests toggle it)
+    const bool fuse_ok = m->opts.genfuse != 0;
     m->x_ready_gen = nullptr;                                            // an assembled input never outlives its call
     for (int s = 0; s < nsteps; ++s) {
+        { int trc = team_settle(m, st); if (trc) return trc; }              // at most one run is ever unsettled
         if (plain && !m->small && large_team_available(m, st)) {
             // a run of steps with no diagnostics increment due inside it and no (u, v, psi) refresh asked of it
             const bool due = m->dg_every > 0 && m->tc >= 1 && m->tc >= m->dg_start && m->tc % m->dg_every == 0;
@@ -422,7 +488,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
                 if (K > 0 && m->dg_every > 0 && t >= 1 && t >= m->dg_start && t % m->dg_every == 0) break;
                 ++K;
             }
-            const int kmin = getenv("QGX_LARGE_TEAM_MIN") ? atoi(getenv("QGX_LARGE_TEAM_MIN")) : 2;   // tuning aid
+            const int kmin = m->opts.team_min;
             if (K >= kmin) {
                 if (due) { int drc = diag_increment(m, nullptr, 1.0, st); if (drc) return drc; }
                 int rc = model_step_run(m, K, st);
@@ -467,7 +533,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
                 // Small grids in layer-split form, GAN / VAE: the generator's output kernel rides in the step kernel's
                 // prologue (unless this step's diagnostics need S first) and — white-in-time Philox noise, more steps to
                 // come in this call — the next step's input kernel in its epilogue (GenFuse, common.hpp)
-                const bool fusable = fuse_ok && m->small && small_layer_split(m->d) && !m->z_double;
+                const bool fusable = fuse_ok && m->small && small_layer_split(m->d, m->opts) && !m->z_double;
                 const bool diag_due = m->dg_every > 0 && m->tc >= 1 && m->tc >= m->dg_start && m->tc % m->dg_every == 0;
                 const bool input_ready = fusable && draw && m->x_ready_gen == (const void *)p->gen && m->x_ready_step == nu.step;
                 m->x_ready_gen = nullptr;

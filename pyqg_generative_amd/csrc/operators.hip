@@ -8,8 +8,6 @@
 #include "common.hpp"
 
 namespace qgx {
-int small_q_to_qh(const SpecDev &d, const double *q, double2 *qh, hipStream_t st);
-int small_qh_to_q(const SpecDev &d, const double2 *qh, double *q, hipStream_t st);
 int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st);
 int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st);
 
@@ -66,13 +64,13 @@ using namespace qgx;
 
 extern "C" int qgx_rfft2(qgx_model *m, const double *x_dev, double *xh_dev, void *stream) {
     QGX_REQUIRE(m && x_dev && xh_dev, "qgx_rfft2: null argument");
-    return m->small ? small_q_to_qh(m->d, x_dev, (double2 *)xh_dev, (hipStream_t)stream)
+    return m->small ? small_q_to_qh(m->d, m->opts, x_dev, (double2 *)xh_dev, (hipStream_t)stream)
                     : large_q_to_qh(m, x_dev, (double2 *)xh_dev, (hipStream_t)stream);
 }
 
 extern "C" int qgx_irfft2(qgx_model *m, const double *xh_dev, double *x_dev, void *stream) {
     QGX_REQUIRE(m && x_dev && xh_dev, "qgx_irfft2: null argument");
-    return m->small ? small_qh_to_q(m->d, (const double2 *)xh_dev, x_dev, (hipStream_t)stream)
+    return m->small ? small_qh_to_q(m->d, m->opts, (const double2 *)xh_dev, x_dev, (hipStream_t)stream)
                     : large_qh_to_q(m, (const double2 *)xh_dev, x_dev, (hipStream_t)stream);
 }
 

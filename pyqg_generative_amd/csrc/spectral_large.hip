@@ -506,7 +506,7 @@ __global__ __launch_bounds__(NT > 0 ? NT : 1024) void k_l_rows_fwd_tend(SpecDev 
 
 // ---- host side ---------------------------------------------------------------------------------
 static int lines_per_block(int N) {
-    static const int forced = getenv("QGX_LARGE_LPB") ? atoi(getenv("QGX_LARGE_LPB")) : 0;   // tuning aid
+    static const int forced = tune_env("QGX_LARGE_LPB", 0);
     if (forced > 0 && N % forced == 0) return forced;
     int lpb = 64;
     // <= 36 KB of LDS per workgroup: 4 workgroups per CU hide the global-memory latency of these
@@ -521,13 +521,13 @@ static size_t lines_lds(int N, int lpb) { return (size_t)lpb * (N + 1) * 16 + (s
 // tile shapes of the three-field kernels of the unparameterized step: columns per tile of k_l_cols3 (3 lines per
 // column) and mirror pairs of rows per workgroup of k_l_rows_build_inv<3> (6 lines per pair)
 static int cols3_cpb(int N) {
-    static const int forced = getenv("QGX_LARGE_C3") ? atoi(getenv("QGX_LARGE_C3")) : 0;       // tuning aid
+    static const int forced = tune_env("QGX_LARGE_C3", 0);
     int c = forced > 0 ? forced : 4;
     while (c > 1 && (N % c || lines_lds(N, 3 * c) > 160 * 1024 - 512)) c /= 2;
     return (N % c == 0 && lines_lds(N, 3 * c) <= 160 * 1024 - 512) ? c : 0;
 }
 static int rows3_ppw(int N) {
-    static const int forced = getenv("QGX_LARGE_P3") ? atoi(getenv("QGX_LARGE_P3")) : 0;
+    static const int forced = tune_env("QGX_LARGE_P3", 0);
     const int p = forced > 0 ? forced : 1;
     return ((N / 2) % p == 0 && lines_lds(N, 6 * p) <= 160 * 1024 - 512) ? p : 1;
 }
@@ -536,7 +536,7 @@ static int rows3_ppw(int N) {
 // A column tile touches N rows at one x offset: with the natural pitch (N * 16 B = 4 KiB at 256) every one of those
 // accesses lands on the same few memory channels.
 int large_zpad() {
-    static const int pad = getenv("QGX_LARGE_ZPAD") ? atoi(getenv("QGX_LARGE_ZPAD")) : 8;
+    static const int pad = tune_env("QGX_LARGE_ZPAD", 8);
     return pad < 0 ? 0 : pad;
 }
 
@@ -596,7 +596,7 @@ static bool fused_transforms_ok(int N, int lpb) { return lpb >= 2 && lpb % 2 == 
 int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st) {
     const SpecDev &d = m->d;
     const int lpb = lines_per_block(d.N);
-    static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+    const bool unfused = !m->opts.large_fused;
     if (!unfused && fused_transforms_ok(d.N, lpb)) {
         const size_t lds = lines_lds(d.N, lpb);
         hipLaunchKernelGGL(k_l_rows_S, dim3(d.B * (d.N / lpb)), dim3(256), lds, st, d, q, m->zbuf, 1.0, lpb);
@@ -617,7 +617,7 @@ int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st) {
 int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st) {
     const SpecDev &d = m->d;
     const int lpb = lines_per_block(d.N);
-    static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+    const bool unfused = !m->opts.large_fused;
     if (!unfused && fused_transforms_ok(d.N, lpb)) {
         const size_t lds = lines_lds(d.N, lpb);
         hipLaunchKernelGGL(k_l_rows_build_inv<1>, dim3(d.B * ((d.N / 2) / (lpb / 2))), dim3(256), lds, st, d, qh, m->zbuf,
@@ -641,7 +641,7 @@ int large_invert(qgx_model *m, hipStream_t st) {
         // fused form: (u, v) spectra built in the row kernel's staging (with psi stored), split into u, v in the column
         // kernel's store — 2 launches instead of 4
         const int lpb = lines_per_block(d.N);
-        static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+        const bool unfused = !m->opts.large_fused;
         if (!unfused && lpb >= 4 && lpb % 4 == 0 && (d.N / 2) % (lpb / 4) == 0 && d.N % lpb == 0) {
             const size_t lds = lines_lds(d.N, lpb);
             hipLaunchKernelGGL(k_l_rows_build_inv<0>, dim3(d.B * ((d.N / 2) / (lpb / 4))), dim3(256), lds, st, d,
@@ -692,7 +692,7 @@ int large_ensure_q(qgx_model *m, hipStream_t st) {
 }
 
 int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
-    static const bool unfused = getenv("QGX_LARGE_UNFUSED") != nullptr;      // A/B aid
+    const bool unfused = !m->opts.large_fused;
     const SpecDev &d = m->d;
     const int lpb = lines_per_block(d.N);
     if (unfused || lpb < 4 || (d.N / 2) % (lpb / 4)) return large_step_unfused(m, a, st);
@@ -701,12 +701,12 @@ int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
     // Unparameterized steps (the 256 x 256 forcing-dataset runs) keep NO real-space q between steps: q = irfft2(qh)
     // rides as a third field through the two kernels that transform (u, v) — 3 launches per step instead of 5, no q
     // write + read, no second read of qh_out; m->q is refreshed on demand (large_ensure_q: snapshots, generator).
-    static const bool eager = getenv("QGX_LARGE_EAGER_Q") != nullptr;        // A/B aid
+    const bool eager = !m->opts.large_lazy_q;
     const int c3 = cols3_cpb(N), ppw = rows3_ppw(N);
     const int zp = N + large_zpad();
     if (!a.has_S && !eager && c3 > 0) {
         const size_t lds1 = lines_lds(N, 6 * ppw), lds2 = lines_lds(N, 3 * c3);
-        static const bool generic = getenv("QGX_LARGE_GENERIC") != nullptr;   // A/B aid: run-time-N kernels
+        const bool generic = !m->opts.large_specialised;      // run-time-N kernels
         double2 *const ph_o = a.diag ? a.ph : (double2 *)nullptr;
         double *const u_o = a.diag ? a.u : (double *)nullptr, *const v_o = a.diag ? a.v : (double *)nullptr;
         // compile-time specialisations; tiles (mirror pairs of rows / columns / pairs per workgroup) and thread counts
@@ -721,8 +721,7 @@ int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
                            d, a, (const double2 *)m->zbuf, P3, zp);                                                   \
     }
 #ifdef QGX_L3_SWEEP      // tuning build: tile / thread variants of the 256 x 256 kernels, picked by environment variables
-        static const int v1 = getenv("QGX_V1") ? atoi(getenv("QGX_V1")) : 0, v2 = getenv("QGX_V2") ? atoi(getenv("QGX_V2")) : 0,
-                         v3 = getenv("QGX_V3") ? atoi(getenv("QGX_V3")) : 0;
+        static const int v1 = tune_env("QGX_V1", 0), v2 = tune_env("QGX_V2", 0), v3 = tune_env("QGX_V3", 0);
         if (!generic && N == 256 && (v1 || v2 || v3)) {
 #define QGX_K1(P, T) hipLaunchKernelGGL((k_l_rows_build_inv<3, 256, P, T>), dim3(B * (128 / P)), dim3(T), lines_lds(256, 6 * P), st, d, a.qh_in, m->zbuf, ph_o, P, zp)
 #define QGX_K2(C, T) hipLaunchKernelGGL((k_l_cols3<256, C, T>), dim3(B * (256 / C)), dim3(T), lines_lds(256, 3 * C), st, d, m->zbuf, u_o, v_o, C, zp)
@@ -738,10 +737,10 @@ int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
         else if (!generic && N == 128) QGX_L3(128, 2, 512, 8, 1024, 4, 512)
         else if (!generic && N == 512) QGX_L3(512, 1, 256, 4, 512, 2, 256)
         else {
-            static const int t1 = getenv("QGX_LARGE_T1") ? atoi(getenv("QGX_LARGE_T1")) : 256;   // tuning aids: threads
-            static const int t2 = getenv("QGX_LARGE_T2") ? atoi(getenv("QGX_LARGE_T2")) : 256;
-            static const int t3 = getenv("QGX_LARGE_T3") ? atoi(getenv("QGX_LARGE_T3")) : 256;
-            static const int p4 = getenv("QGX_LARGE_P4") ? atoi(getenv("QGX_LARGE_P4")) : 0;     // row pairs of the tendency kernel
+            static const int t1 = tune_env("QGX_LARGE_T1", 256);   // tuning aids (A/B library): threads
+            static const int t2 = tune_env("QGX_LARGE_T2", 256);
+            static const int t3 = tune_env("QGX_LARGE_T3", 256);
+            static const int p4 = tune_env("QGX_LARGE_P4", 0);     // row pairs of the tendency kernel
             const int ppw4 = p4 > 0 && (N / 2) % p4 == 0 ? p4 : lpb / 4;
             hipLaunchKernelGGL(k_l_rows_build_inv<3>, dim3(B * ((N / 2) / ppw)), dim3(t1), lds1, st, d, a.qh_in, m->zbuf,
                                ph_o, ppw, zp);
@@ -1191,8 +1190,7 @@ static size_t team_lds(int N) {
 
 // 1: the device runs 8 teams of 32 co-resident workgroups (census passed), 0: it does not.  Decided once per model.
 int large_team_available(qgx_model *m, hipStream_t st) {
-    const bool off = getenv("QGX_LARGE_NO_TEAM") != nullptr;                 // A/B aid (read per call: tests toggle it)
-    if (off || m->N != 256 || m->B < 1) return 0;
+    if (!m->opts.team || m->N != 256 || m->B < 1) return 0;
     if (m->team_state != 0) return m->team_state > 0;
     m->team_state = -1;
     hipDeviceProp_t prop;
@@ -1213,8 +1211,11 @@ int large_team_available(qgx_model *m, hipStream_t st) {
     return m->team_state > 0;
 }
 
-// a finished run must have raised no flag (barrier time-out, census changed under our feet): loud, not silent
-int large_team_check(qgx_model *m, hipStream_t st) {
+// reads back the flag word of the pending run (one stream synchronisation): *flag = 0 if the run completed, else what
+// stopped it (1: a team barrier timed out, 2: workgroups not co-resident, 3: census changed).  The caller
+// (model.hip::team_settle) undoes and replays a flagged run.
+int large_team_check(qgx_model *m, hipStream_t st, unsigned *flag) {
+    *flag = 0;
     if (!m->team_pending) return QGX_OK;
     m->team_pending = false;
     TeamCtl h;
@@ -1229,30 +1230,26 @@ int large_team_check(qgx_model *m, hipStream_t st) {
         fprintf(stderr, " total %.2f\n", (double)(long long)(h.stamps[13] - h.stamps[0]) / 100.0);
     }
 #endif
-    if (h.err != 0) {
-        m->team_state = -1;
-        set_error("XCD-resident step kernel raised flag %u (1: team barrier timed out, 2: workgroups not co-resident, "
-                  "3: census changed); the model state is undefined", h.err);
-        return QGX_ERR_HIP;
-    }
+    *flag = h.err;
     return QGX_OK;
 }
 
 // K consecutive unparameterized steps without diagnostics output; coef[level] = (dt1, dt2, dt3)
 int large_team_steps(qgx_model *m, int K, int ablevel0, const double coef[3][3], const double2 *qh_src, double2 *qh_dst,
                      const double2 *p_src, const double2 *pp_src, double2 *p_dst, double2 *pp_dst, hipStream_t st) {
-    int rc = large_team_check(m, st);
-    if (rc) return rc;
+    QGX_REQUIRE(!m->team_pending, "large_team_steps: the previous run has not been settled");
     TeamArgs a{};
     a.qh_src = qh_src; a.qh_dst = qh_dst; a.p_src = p_src; a.pp_src = pp_src; a.p_dst = p_dst; a.pp_dst = pp_dst;
     a.X = m->zbuf; a.ctl = (TeamCtl *)m->team_ctl;
     a.nsteps = K; a.ablevel0 = ablevel0; a.ZP = m->N + large_zpad(); a.census_only = 0;
-    a.fault = getenv("QGX_TEAM_FAULT") != nullptr;       // test hook: the flag path of large_team_check
+    a.fault = m->opts.team_fault;       // test hook (A/B library): the flag path of large_team_check
+    m->opts.team_fault = 0;
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a.c[i][j] = coef[i][j];
     QGX_HIP(hipMemsetAsync(m->team_ctl, 0, sizeof(TeamCtl), st));
     hipLaunchKernelGGL((k_l_team_steps<256>), dim3(8 * TEAM_WG), dim3(TEAM_NT), team_lds(256), st, m->d, a);
     QGX_HIP(hipGetLastError());
     m->team_pending = true;
+    m->team_stream = st;
     m->q_stale = true;
     return QGX_OK;
 }

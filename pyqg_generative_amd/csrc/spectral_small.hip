@@ -382,7 +382,8 @@ __global__ void k_invert_small(SpecDev d, const double2 *qh, double2 *ph, double
 // k_diag_products, k_q_to_qh_small, k_diag_scale_S and k_diag_accumulate, expression by expression.
 template <int NN>
 __global__ void k_diag_small(SpecDev d, DiagConst c, const double2 *qh, double2 *ph, double *u, double *v, double *P, double *XI,
-                             double2 *S3, double2 *S4, double2 *S5, double2 *Sh, const double *S, double weight, DiagAcc acc) {
+                             double2 *S3, double2 *S4, double2 *S5, double2 *Sh, double2 *S6, double2 *S7, const double *S, double weight,
+                             const double *q, const double2 *dq_p, const double2 *dq_pp, DiagAcc acc) {
     double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
     int *pos_lds;
     Grid g = make_grid(d, Z, pos_lds);
@@ -432,9 +433,9 @@ __global__ void k_diag_small(SpecDev d, DiagConst c, const double2 *qh, double2 
         XI[ro + rz + idx] = w.y;
     }
     __syncthreads();
-    // ---- the three pairs of products and the forcing, each: stage the pair, forward transform, unpack
-    for (int which = 0; which < 4; ++which) {
-        if (which == 3 && !S) break;
+    // ---- the five pairs of products and the forcing, each: stage the pair, forward transform, unpack
+    for (int which = 0; which < 6; ++which) {
+        if (which == 3 && !S) continue;
         for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
             const int y = idx / N, x = idx - y * N;
             const size_t o = ro + idx;
@@ -450,14 +451,20 @@ __global__ void k_diag_small(SpecDev d, DiagConst c, const double2 *qh, double2 
             } else if (which == 2) {
                 const double x2 = XI[o + rz];
                 ra = u[o + rz] * x2; rb = v[o + rz] * x2;
-            } else {
+            } else if (which == 3) {
                 ra = weight * S[o]; rb = weight * S[o + rz];
+            } else if (which == 4) {            // (u_1 q_1, v_1 q_1): the enstrophy flux and the tendency of Dissspec
+                const double q1 = q[o];
+                ra = u[o] * q1; rb = v[o] * q1;
+            } else {
+                const double q2 = q[o + rz];
+                ra = u[o + rz] * q2; rb = v[o + rz] * q2;
             }
             Z[y * LD + x] = make_double2(ra, rb);
         }
         __syncthreads();
         fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
-        double2 *dst = which == 0 ? S3 : (which == 1 ? S4 : (which == 2 ? S5 : Sh));
+        double2 *dst = which == 0 ? S3 : (which == 1 ? S4 : (which == 2 ? S5 : (which == 3 ? Sh : (which == 4 ? S6 : S7))));
         for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
             const int j = idx / NK, i = idx - j * NK;
             double2 s0, s1;
@@ -473,7 +480,8 @@ __global__ void k_diag_small(SpecDev d, DiagConst c, const double2 *qh, double2 
         const size_t o = so + idx, o2 = (size_t)b * sz + idx;
         const double2 zero = make_double2(0., 0.);
         diag_accumulate_elem(d, c, acc, idx, i, j, o, o2, sz, qh[o], qh[o + sz], ph[o], ph[o + sz], S3[o], S3[o + sz], S4[o], S4[o + sz],
-                             S5[o], S5[o + sz], S != nullptr, S ? Sh[o] : zero, S ? Sh[o + sz] : zero);
+                             S5[o], S5[o + sz], S != nullptr, S ? Sh[o] : zero, S ? Sh[o + sz] : zero, S6[o], S6[o + sz], S7[o], S7[o + sz],
+                             dq_p[o], dq_p[o + sz], dq_pp[o], dq_pp[o + sz]);
     }
 }
 
@@ -482,9 +490,8 @@ static size_t small_lds_bytes(const SpecDev &d) {
     size_t bytes = (size_t)d.N * d.LD * sizeof(double2) + (size_t)((d.N + 3) & ~3) * sizeof(int) + (size_t)d.N * sizeof(double2);
     return (bytes + 15) & ~(size_t)15;
 }
-static int small_threads(const SpecDev &d) {
-    static const int forced = getenv("QGX_SPEC_THREADS") ? atoi(getenv("QGX_SPEC_THREADS")) : 0;   // tuning aid
-    if (forced > 0) return forced;
+static int small_threads(const SpecDev &d, const ModelOpts &o) {
+    if (o.spec_threads > 0) return o.spec_threads;
     // One workgroup advances one member.  With at most one member per CU the kernel is a latency chain
     // (about 50 barriers): 1024 threads shorten it (B=128, N=64: 119 -> 71 us); with several members
     // queued per CU 512 threads give the best throughput (B=1024: 293 us vs 385 @256 / 337 @1024).
@@ -522,43 +529,40 @@ int small_prepare(const SpecDev &d) {
 }
 
 // two workgroups per member (one per layer) while all of them are resident at once
-bool small_layer_split(const SpecDev &d);
-static bool layer_split(const SpecDev &d) { return small_layer_split(d); }
-bool small_layer_split(const SpecDev &d) {
-    static const int forced = getenv("QGX_SPEC_LSPLIT") ? atoi(getenv("QGX_SPEC_LSPLIT")) : -1;   // tuning aid
-    if (forced >= 0) return forced != 0;
+bool small_layer_split(const SpecDev &d, const ModelOpts &o) {
+    if (o.lsplit >= 0) return o.lsplit != 0;
     return 2 * d.B <= 256;      // one workgroup per CU (measured at 64x64: B = 128 44 -> 33 us, B = 256 55 -> 63 us)
 }
 
-int small_step(const SpecDev &d, const StepArgs &a, hipStream_t st) {
-    if (layer_split(d)) {
+int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStream_t st) {
+    if (small_layer_split(d, o)) {
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else {
-        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_step_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, a))
+        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_step_small<NN>, dim3(d.B), dim3(small_threads(d, o)), small_lds_bytes(d), st, d, a))
     }
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
-int small_q_to_qh(const SpecDev &d, const double *q, double2 *qh, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_q_to_qh_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, q, qh))
+int small_q_to_qh(const SpecDev &d, const ModelOpts &o, const double *q, double2 *qh, hipStream_t st) {
+    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_q_to_qh_small<NN>, dim3(d.B), dim3(small_threads(d, o)), small_lds_bytes(d), st, d, q, qh))
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
-int small_qh_to_q(const SpecDev &d, const double2 *qh, double *q, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_qh_to_q_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, qh, q))
+int small_qh_to_q(const SpecDev &d, const ModelOpts &o, const double2 *qh, double *q, hipStream_t st) {
+    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_qh_to_q_small<NN>, dim3(d.B), dim3(small_threads(d, o)), small_lds_bytes(d), st, d, qh, q))
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
-int small_invert(const SpecDev &d, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st) {
-    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_invert_small<NN>, dim3(d.B), dim3(small_threads(d)), small_lds_bytes(d), st, d, qh, ph, u, v))
+int small_invert(const SpecDev &d, const ModelOpts &o, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st) {
+    QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_invert_small<NN>, dim3(d.B), dim3(small_threads(d, o)), small_lds_bytes(d), st, d, qh, ph, u, v))
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }
 int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
-                         double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, const double *S, double weight,
-                         const DiagAcc &a, hipStream_t st) {
+                         double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, double2 *S6, double2 *S7, const double *S,
+                         double weight, const double *q, const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st) {
     QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_diag_small<NN>, dim3(d.B), dim3(1024), small_lds_bytes(d), st, d, c, qh, ph, u, v, P, XI,
-                                           S3, S4, S5, Sh, S, weight, a))
+                                           S3, S4, S5, Sh, S6, S7, S, weight, q, dq_p, dq_pp, a))
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }

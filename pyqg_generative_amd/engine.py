@@ -79,8 +79,7 @@ class Generator:
 
     def range_ok(self):
         """-> None if every value stayed inside the 16-bit window since the last check, else a description."""
-        if self.info()['precision'] == 0:
-            self.range_read()
+        if self.precision == 0:          # exact-f32 kernels store no 16-bit activations: nothing to read, no synchronisation
             return None
         flags, in_max = self.range_read()
         if flags == 0 and in_max <= 65504.:
@@ -103,6 +102,25 @@ class Generator:
         return out
 
     check_range = True
+
+    def guarded_loop(self, body):
+        """Run `body()` — a loop of many forward launches (Monte-Carlo sampling, minibatches) — with ONE range check
+        after it instead of a device-to-host read and a stream synchronisation per launch; if the 16-bit window was left
+        anywhere in the loop, switch to the exact-f32 kernels for good and run the whole loop again."""
+        if not self.check_range:
+            return body()
+        self.check_range = False
+        try:
+            out = body()
+            why = self.range_ok()
+            if why is not None:
+                import warnings
+                warnings.warn(why + '; switching this generator to the exact-f32 kernels', RuntimeWarning)
+                self.set_option('precision', 0)
+                out = body()
+        finally:
+            del self.check_range            # back to the class default
+        return out
 
     def forward(self, q, z, demean=True, out=None):
         """q: (B,2,N,N) float64 cuda; z: (B,2,N,N) float32 (float64 for gz) -> S (B,2,N,N) float64."""
@@ -130,6 +148,15 @@ class Generator:
 
     def set_option(self, name, value):
         check(lib.qgx_generator_set_option(self._h, name.encode(), int(value)))
+        if name in ('precision', 'auto'):
+            self._precision = None
+
+    @property
+    def precision(self):
+        """arithmetic of the kernels in use: 0 exact f32, 3 f16x3 (cached: asked after every guarded launch)"""
+        if getattr(self, '_precision', None) is None:
+            self._precision = self.info()['precision']
+        return self._precision
 
     def profile(self, layer):
         """Bracket every launch of conv layer `layer` (0..7; -1 = off) with HIP events."""
@@ -156,8 +183,11 @@ class Generator:
 class EnsembleEngine:
     """B independent two-layer QG members resident on one GPU."""
 
-    def __init__(self, nx=64, n_members=1, device=0, **params):
+    def __init__(self, nx=64, n_members=1, device=0, plan_only=False, **params):
+        """plan_only: an FFT plan of the grid for rfft2 / irfft2 (tools/operators.py::Dev) — tables and work space, no
+        model state, a tenth of the device memory and of the creation time of a model"""
         cfg = _lib.qgx_config()
+        cfg.plan_only = int(bool(plan_only))
         p = dict(PYQG_DEFAULTS)
         for k, v in params.items():
             if k not in p:
@@ -227,6 +257,10 @@ class EnsembleEngine:
     def reset_time(self):
         check(lib.qgx_reset_time(self._h))
 
+    def set_option(self, name, value):
+        """kernel-path switch of this model (include/qgx.h::qgx_set_option): same results, different fusion / tiling"""
+        check(lib.qgx_set_option(self._h, name.encode(), int(value)))
+
     def status(self):
         """-> (KE[B], CFL[B]) as pyqg's _print_status computes them (from the last inversion)."""
         out = torch.empty((self.B, 2), dtype=torch.float64, device=self.device)
@@ -238,6 +272,7 @@ class EnsembleEngine:
     def check_generators(self):
         """The fused step cannot re-run a forcing after the fact: a generator that left its 16-bit window since the
         last check has corrupted the members' state, so this raises (status / snapshot cadence of the run loop)."""
+        self._generators = [g for g in self._generators if g._h]        # a closed generator has nothing left to report
         for g in self._generators:
             why = g.range_ok() if g.check_range else None
             if why is not None:

@@ -15,6 +15,14 @@ class _LatentCNN(Parameterization):
     def generate_latent_noise(self, ny, nx):
         return np.random.randn(1, self.n_latent, ny, nx).astype('float32')
 
+    def generate(self, x, z=None):
+        """device tensors: normalised PV x (B,2,Ny,Nx) and latent noise z (B,n_latent,Ny,Nx; drawn here if omitted) ->
+        normalised forcing (cgan_regression.py:133-137, cvae_regression.py:114-118); the `fun` the reference passes to
+        apply_function"""
+        if z is None:
+            z = torch.randn((x.shape[0], self.n_latent, x.shape[2], x.shape[3]), device=x.device)
+        return getattr(self, self.NET_NAMES[0])(torch.cat([x, z.to(x.dtype)], dim=1))
+
     def predict_mean_snapshot(self, m, M=100, seed=None):
         """Deterministic sampling: the mean of M forcing realisations for ONE PV snapshot
         (cgan_regression.py:164-171, cvae_regression.py:138-145).  seed=None draws the latent noise from
@@ -27,7 +35,7 @@ class _LatentCNN(Parameterization):
         X = self.x_scale.normalize(q.astype('float32'))                  # (1,2,N,N)
         if seed is None:
             z = np.random.randn(M, self.n_latent, q.shape[-2], N).astype('float32')
-            Y = apply_function(self._gen, np.tile(X, (M, 1, 1, 1)), z).mean(0, keepdims=True)
+            Y = apply_function(getattr(self, self.NET_NAMES[0]), np.tile(X, (M, 1, 1, 1)), z, fun=self.generate).mean(0, keepdims=True)
         else:
             from .._lib import lib, check
             from ..engine import _ptr, _stream
@@ -72,14 +80,20 @@ class _LatentCNN(Parameterization):
             z = torch.empty((b, 2, N, N), dtype=torch.float32, device='cuda')
             ssum = torch.zeros((b, 2, N, N), dtype=torch.float64, device='cuda')
             ssq = torch.zeros_like(ssum)
-            first = None
-            for m in range(M):
-                check(lib.qgx_noise_normal(_ptr(z), 0, b, 2 * N * N, int(seed), s0, m, 0.0, 1.0, _stream()))
-                x[:, 2:] = z
-                y = self._gen.cnn_forward(x)
-                if first is None:
-                    first = y.clone()
-                check(lib.qgx_moments_accumulate(_ptr(y), _ptr(ssum), _ptr(ssq), y.numel(), _stream()))
+
+            def draws():                    # M launches back to back; the range guard is read once after them
+                ssum.zero_()
+                ssq.zero_()
+                first = None
+                for m in range(M):
+                    check(lib.qgx_noise_normal(_ptr(z), 0, b, 2 * N * N, int(seed), s0, m, 0.0, 1.0, _stream()))
+                    x[:, 2:] = z
+                    y = self._gen.cnn_forward(x)
+                    if first is None:
+                        first = y.clone()
+                    check(lib.qgx_moments_accumulate(_ptr(y), _ptr(ssum), _ptr(ssq), y.numel(), _stream()))
+                return first
+            first = self._gen.guarded_loop(draws)
             sm, sq = ssum.cpu().numpy(), ssq.cpu().numpy()
             mu = sm / M
             sample[s0:s0 + b] = first.cpu().numpy().astype('float64') * ys
@@ -90,6 +104,7 @@ class _LatentCNN(Parameterization):
 
 class CGANRegression(_LatentCNN):
     kind = 'gan'
+    NET_NAMES = ('G',)
 
     def __init__(self, regression='None', nx=64, generator='Andrew', folder='model', div=False,
                  hidden_channels=[128, 64, 32, 32, 32, 32, 32], device=0):

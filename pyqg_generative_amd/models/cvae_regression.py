@@ -6,6 +6,7 @@ from .cgan_regression import _LatentCNN
 
 class CVAERegression(_LatentCNN):
     kind = 'vae'
+    NET_NAMES = ('decoder',)
 
     def __init__(self, regression='None', folder='model', div=False, decoder_var='adaptive', device=0, **kw):
         if regression != 'None' or div:

@@ -9,6 +9,7 @@ from ..tools.cnn_tools import apply_function
 
 class MeanVarModel(Parameterization):
     kind = 'gz'
+    NET_NAMES = ('net_mean', 'net_var')
 
     def __init__(self, folder='model', hidden_channels=[128, 64, 32, 32, 32, 32, 32], device=0):
         if list(hidden_channels) != [128, 64, 32, 32, 32, 32, 32]:
@@ -21,7 +22,7 @@ class MeanVarModel(Parameterization):
 
     def predict_mean_snapshot(self, m, M=100):
         X = self.x_scale.normalize(np.asarray(m.q, 'float64').astype('float32'))
-        return self.y_scale.denormalize(apply_function(self._gen, X, inet=0)).squeeze().astype('float64')
+        return self.y_scale.denormalize(apply_function(self.net_mean, X)).squeeze().astype('float64')
 
     def predict(self, ds, M=1000, seed=None):
         """mean_var_model.py:117-135: mean net, softplus variance net, one Gaussian sample."""
@@ -29,8 +30,8 @@ class MeanVarModel(Parameterization):
         xr = dataset_backend()
         qv = np.asarray(ds['q'].values)
         X = self.x_scale.normalize(qv.reshape((-1,) + qv.shape[2:]).astype('float32'))
-        mean = self.y_scale.denormalize(apply_function(self._gen, X, inet=0)).reshape(qv.shape)
-        var = self.y_scale.denormalize_var(np.logaddexp(0, apply_function(self._gen, X, inet=1))).reshape(qv.shape)
+        mean = self.y_scale.denormalize(apply_function(self.net_mean, X)).reshape(qv.shape)
+        var = self.y_scale.denormalize_var(np.logaddexp(0, apply_function(self.net_var, X))).reshape(qv.shape)
         rng = np.random if seed is None else np.random.RandomState(seed)
         Y = mean + np.sqrt(var) * rng.randn(*var.shape)
         dims = ['run', 'time', 'lev', 'y', 'x']

@@ -13,7 +13,7 @@ import torch
 from ..qgmodel import QParameterization
 from ..engine import Generator
 from .. import weights as _weights
-from ..tools.cnn_tools import ChannelwiseScaler
+from ..tools.cnn_tools import ChannelwiseScaler, DeviceNet
 
 
 class Parameterization(QParameterization):
@@ -25,6 +25,15 @@ class Parameterization(QParameterization):
         self.x_scale = ChannelwiseScaler(xs)
         self.y_scale = ChannelwiseScaler(ys)
         self._gen = Generator(self.kind, nets, xs, ys, device=device)
+        self._bind_nets()
+
+    NET_NAMES = ()       # the reference's attribute names of the nets, in the generator's net order
+
+    def _bind_nets(self):
+        """the reference's model objects expose their torch modules (G / decoder / net_mean, net_var); notebooks hand
+        them to apply_function(net, *X, fun=...) — here handles on the device-resident nets (tools/cnn_tools.py)"""
+        for inet, name in enumerate(self.NET_NAMES):
+            setattr(self, name, DeviceNet(self._gen, inet))
 
     @classmethod
     def from_arrays(cls, nets, x_std, y_std, device=0, **kw):
@@ -36,6 +45,7 @@ class Parameterization(QParameterization):
         self.x_scale = ChannelwiseScaler(x_std)
         self.y_scale = ChannelwiseScaler(y_std)
         self._gen = Generator(cls.kind, nets, x_std, y_std, device=device)
+        self._bind_nets()
         return self
 
     def device_generator(self):

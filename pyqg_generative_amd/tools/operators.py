@@ -29,10 +29,13 @@ class Dev:
 
     FFT plans and inversion models are engines (device allocations) kept in ONE keyed LRU cache:
     ('fft', N, M, device) or ('inv', N, B, device, params).  ``Dev.close()`` frees everything;
-    the least recently used engine is closed when more than ``MAX_PLANS`` are alive, so sweeping many
-    resolutions x operators (generate_subgrid_forcing) does not accumulate device memory."""
+    the least recently used engine is closed when more than ``MAX_PLANS`` are alive.  The cache must hold the WORKING
+    SET of one snapshot of the reference's own forcing-dataset run or every lookup of its cyclic access pattern misses
+    (run_forcing_datasets.py: Nc = [32, 48, 64, 96, 128] with the 3/2-rule keeps 15 keys live — transforms of 384, 32,
+    48, 64, 96, 128, 72, 144, 192 and inversions of 256, 32, 48, 64, 96, 128); transform plans are state-less handles
+    (``plan_only``: tables + work space), so 64 of them cost little."""
     L = 1e6
-    MAX_PLANS = 12
+    MAX_PLANS = 64
     _plans = collections.OrderedDict()
     _tables = {}
     _PARAM_KEYS = ('rek', 'delta', 'beta', 'rd', 'U1', 'U2', 'H1', 'L')
@@ -53,7 +56,7 @@ class Dev:
     @classmethod
     def plan(cls, N, M, device=0):
         return cls._engine(('fft', N, M, device),
-                           lambda: EnsembleEngine(nx=N, n_members=M // 2, device=device, L=cls.L))
+                           lambda: EnsembleEngine(nx=N, n_members=M // 2, device=device, L=cls.L, plan_only=True))
 
     @classmethod
     def inversion_model(cls, N, B, device, pyqg_params):

@@ -167,14 +167,54 @@ def generate_subgrid_forcing(Nc, pyqg_params, sampling_freq=ANDREW_1000_STEPS, n
     return out
 
 
+def forecast_statistics(ds, n_local, xr=None, group=None):
+    """Member 0 and the ensemble mean over ALL members of the job of q, u, v, psi (reference:
+    ``ds[var].isel(run=0)`` / ``ds[var].mean('run')``, simulate.py:284-290).  ``ds`` holds this rank's members along
+    'run'.  Single process: a local mean.  Several ranks (torch.distributed initialised; members sharded in contiguous
+    blocks, rank 0 first): ONE all-reduce of the per-rank partial sums of the four fields together
+    (parallel.ensemble_mean — the path's only collective) and one broadcast of member 0 from rank 0, so that every rank
+    returns the same dataset."""
+    import torch
+    import torch.distributed as dist
+    from .. import parallel
+    xr = xr or dataset_backend()
+    names = ('q', 'u', 'v', 'psi')
+    out = xr.Dataset(attrs=dict(ds.attrs))
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        for var in names:
+            out[var] = ds[var].isel(run=0)
+            out[var + '_mean'] = ds[var].mean('run')
+        return out
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    run_axis = ds['q'].dims.index('run')
+    local = torch.stack([torch.as_tensor(np.asarray(ds[v].values, dtype=np.float64)).sum(run_axis) for v in names]).to(dev)
+    mean = parallel.ensemble_mean(local, n_local, group).cpu().numpy()
+    first = torch.stack([torch.as_tensor(np.take(np.asarray(ds[v].values, dtype=np.float64), 0, axis=run_axis)) for v in names]).to(dev)
+    dist.broadcast(first, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    first = first.cpu().numpy()
+    dims = tuple(d for d in ds['q'].dims if d != 'run')
+    for i, var in enumerate(names):
+        out[var] = (dims, first[i].astype(ds[var].dtype))
+        out[var + '_mean'] = (dims, mean[i].astype(ds[var].dtype))
+    for c in dims:
+        if c in ds.variables:
+            out[c] = ds[c]
+    return out
+
+
 def run_forecast(pyqg_params, parameterization, q_init, n_ens, operator=None, sampling_freq=DAY, device=0, seed=0):
     """Forecast mode (reference: simulate.py:254-293): the initial PV is a snapshot of a high-resolution
     run, coarse-grained to the model's grid with ``operator`` ('Operator1' | 'Operator2' | 'Operator4' |
     'Operator5' or the function itself; None / failure to apply = ``q_init`` is used as it is, as the
     reference's try/except does, simulate.py:269-273); ``n_ens`` members start from it and differ only in
     the latent noise.  The reference runs them one after another and averages with xarray
-    (simulate.py:279-290); here they advance together on the GPU.  Returns a Dataset holding q, u, v, psi
-    of member 0 and the ensemble means q_mean, u_mean, v_mean, psi_mean, each (time, lev, y, x)."""
+    (simulate.py:279-290); here they advance together on the GPU — and, when torch.distributed is initialised
+    (one process per GPU), each rank advances its contiguous block of the ``n_ens`` members (noise streams keyed by
+    the global member id) and the mean is formed by one all-reduce (forecast_statistics).  Returns a Dataset
+    holding q, u, v, psi of member 0 and the ensemble means q_mean, u_mean, v_mean, psi_mean, each (time, lev, y, x)."""
+    import torch.distributed as dist
+    from .. import parallel
     xr = dataset_backend()
     q_init = np.asarray(q_init, dtype='float64')
     nx = int(pyqg_params['nx'])
@@ -182,12 +222,13 @@ def run_forecast(pyqg_params, parameterization, q_init, n_ens, operator=None, sa
         from . import operators as ops
         op = getattr(ops, operator) if isinstance(operator, str) else operator
         q_init = op(q_init, nx)
+    first, n_local = 0, n_ens
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        first, n_local = parallel.shard_members(n_ens, dist.get_rank(), dist.get_world_size())
+        if n_local < 1:
+            raise ValueError(f'n_ens={n_ens} leaves rank {dist.get_rank()} without a member')
     ds = run_simulation(pyqg_params, parameterization, q_init=q_init, sampling_freq=sampling_freq,
-                        n_members=n_ens, device=device, seed=seed)[['q', 'u', 'v', 'psi']]
-    if n_ens == 1:
+                        n_members=n_local, device=device, seed=seed, member_offset=first)[['q', 'u', 'v', 'psi']]
+    if n_local == 1:
         ds = ds.expand_dims('run')
-    out = xr.Dataset(attrs=dict(ds.attrs))
-    for var in ('q', 'u', 'v', 'psi'):
-        out[var] = ds[var].isel(run=0)
-        out[var + '_mean'] = ds[var].mean('run')
-    return out
+    return forecast_statistics(ds, n_local, xr)

@@ -63,6 +63,12 @@ DIAGNOSTICS = {
     'paramspec': (('l', 'k'), 'm^2 s^-3', 'spectral contribution of subgrid parameterization to energy (if present)'),
     'paramspec_APEflux': (('l', 'k'), 'm^2 s^-3', 'total additional APE flux due to subgrid parameterization'),
     'paramspec_KEflux': (('l', 'k'), 'm^2 s^-3', 'total additional KE flux due to subgrid parameterization'),
+    'Dissspec': (('l', 'k'), 'm^2 s^-3', 'Spectral contribution of filter dissipation to total energy'),
+    'ENSDissspec': (('l', 'k'), 's^-3', 'Spectral contribution of filter dissipation to barotropic enstrophy'),
+    'ENSflux': (('l', 'k'), 's^-3', 'barotropic enstrophy flux'),
+    'ENSgenspec': (('l', 'k'), 's^-3', 'the spectrum of the rate of generation of barotropic enstrophy'),
+    'ENSfrictionspec': (('l', 'k'), 's^-3', 'the spectrum of the rate of dissipation of barotropic enstrophy due to bottom friction'),
+    'ENSparamspec': (('l', 'k'), 's^-3', 'Spectral contribution of subgrid parameterization to enstrophy'),
 }
 
 # model attributes exported as global attributes "pyqg:<name>"

@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""Test helper (imports the oracle, so it lives under tests/): the reference's ONLINE METRICS (Google-Colab/online-simulations.ipynb cells 6, 11-14, 29-33) from runs
+"""Helper MODULE of tests/test_gpu_online_metrics.py (not an experiment script: the test imports `run`; it scores with
+oracle/metrics_ref.py, and only tests/ may import the oracle): the reference's ONLINE METRICS (Google-Colab/online-simulations.ipynb cells 6, 11-14, 29-33) from runs
 of this engine: a 256 x 256 reference run coarse-grained with Operator1 to 48 x 48 (the notebook's `eddy/48/hires-sharp`),
 48 x 48 runs without parameterization (`lores`) and with the shipped CGAN / CVAE / GZ models (AR1, nsteps = 1), 20 years
 each, and the distributional / spectral errors of oracle/metrics_ref.py.
-    python tests/online_metrics_experiment.py [members per low-resolution case] [hires members] [cases]"""
+    python tests/online_metrics_protocol.py [members per low-resolution case] [hires members] [cases]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -43,3 +43,49 @@ def test_single_process_ensemble_mean_is_local_mean():
     from pyqg_generative_amd import parallel
     x = torch.arange(24, dtype=torch.float64).reshape(2, 3, 4)
     np.testing.assert_allclose(parallel.ensemble_mean(x * 5, 5).numpy(), x.numpy())
+
+
+def _forecast_worker(rank, world, port, total, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from pyqg_generative_amd import parallel
+    from pyqg_generative_amd.tools import xr_lite as xr
+    from pyqg_generative_amd.tools.simulate import forecast_statistics
+    dist = parallel.init_process_group('gloo')
+    first, n = parallel.shard_members(total, rank, world)
+    data = _forecast_fields(total)[first:first + n]                       # this rank's members: (n, 4, time, lev, y, x)
+    ds = xr.Dataset({v: (('run', 'time', 'lev', 'y', 'x'), data[:, i].astype(np.float32)) for i, v in enumerate(('q', 'u', 'v', 'psi'))},
+                    coords={'time': (('time',), np.arange(3, dtype=np.float32))}, attrs={'pyqg_params': 'x'})
+    out = forecast_statistics(ds, n, xr)
+    np.savez(os.path.join(tmp, f'fc{rank}.npz'), **{k: np.asarray(out[k].values) for k in out.keys()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _forecast_fields(total):
+    rs = np.random.RandomState(3)
+    return rs.randn(total, 4, 3, 2, 4, 4)
+
+
+def test_two_rank_forecast_mean_uses_the_collective(tmp_path):
+    """run_forecast's ensemble statistics with the members sharded over two ranks (5 = 3 + 2): every rank returns member 0
+    (broadcast from rank 0) and the mean over ALL members (one all-reduce of partial sums), equal to the single-process
+    result (reference: ds[var].mean('run'), simulate.py:284-290)"""
+    total, world, port = 5, 2, 29617
+    mp.spawn(_forecast_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    data = _forecast_fields(total).astype(np.float32)
+    for r in range(world):
+        got = np.load(tmp_path / f'fc{r}.npz')
+        for i, v in enumerate(('q', 'u', 'v', 'psi')):
+            assert got[v].shape == (3, 2, 4, 4) and got[v].dtype == np.float32
+            np.testing.assert_array_equal(got[v], data[0, i])
+            np.testing.assert_allclose(got[v + '_mean'], data[:, i].astype(np.float64).mean(0), rtol=1e-6, atol=1e-7)
+    # single process: the local mean, same keys
+    sys.path.insert(0, ROOT)
+    from pyqg_generative_amd.tools import xr_lite as xr
+    from pyqg_generative_amd.tools.simulate import forecast_statistics
+    ds = xr.Dataset({v: (('run', 'time', 'lev', 'y', 'x'), data[:, i]) for i, v in enumerate(('q', 'u', 'v', 'psi'))})
+    one = forecast_statistics(ds, total, xr)
+    assert sorted(one.keys()) == sorted(np.load(tmp_path / 'fc0.npz').files)
+    np.testing.assert_allclose(np.asarray(one['q_mean'].values), np.load(tmp_path / 'fc1.npz')['q_mean'], rtol=1e-6, atol=1e-7)

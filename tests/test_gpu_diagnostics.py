@@ -33,7 +33,8 @@ def test_time_averaged_diagnostics_match_oracle(N):
         r.run()
         refs.append(r)
     assert m.diagnostics_count == refs[0].diag_count == len([t for t in range(1, nsteps) if t >= 8 and t % 3 == 0])
-    for name in ('KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec'):
+    for name in ('KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec',
+                 'Dissspec', 'ENSDissspec', 'ENSflux', 'ENSgenspec', 'ENSfrictionspec'):
         got = m.get_diagnostic(name)
         for b in range(B):
             ref = refs[b].get_diagnostic(name)
@@ -74,8 +75,17 @@ def test_paramspec_and_dataset_export():
         assert np.abs(g - rr).max() <= 1e-9 * np.abs(rr).max(), name
         parts = parts + g
     assert np.abs(parts - got).max() <= 1e-10 * np.abs(got).max()
+    # the enstrophy budget and the filter's dissipation with a parameterization in the tendency (Dissspec uses the
+    # tendency the step is about to take, forcing included): all sixteen keys of comparison_tools.py:222-225
+    from pyqg_generative_amd._lib import DIAGS
+    assert len(DIAGS) == 16
+    for name in DIAGS:
+        g, rr = m.get_diagnostic(name), r.get_diagnostic(name)
+        assert g.shape == rr.shape and np.abs(g - rr).max() <= 1e-9 * np.abs(rr).max(), name
     ds = snapshot_dataset(m)           # one snapshot: pyqg's layout, every variable with a length-one time axis
     assert ds['KEspec'].shape == (1, 2, N, N // 2 + 1) and ds['KEflux'].shape == (1, N, N // 2 + 1)
+    for key in ('Dissspec', 'ENSDissspec', 'ENSflux', 'ENSfrictionspec', 'ENSgenspec', 'ENSparamspec'):
+        assert ds[key].shape == (1, N, N // 2 + 1), key
     assert ds['q'].shape == (1, 2, N, N)
     from pyqg_generative_amd.tools.simulate import concat_in_time
     full = concat_in_time([ds, ds])    # the run's dataset: spectra from the last snapshot, no time axis

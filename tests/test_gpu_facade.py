@@ -363,24 +363,30 @@ def test_offline_monte_carlo_moments(tmp_path):
     assert np.abs(var[0] - ys.var(0, ddof=1)).max() < 2e-4 * ys.var(0, ddof=1).max()
 
 
-def test_bench_two_rank_rehearsal_over_gloo():
+@pytest.mark.parametrize('mode', ['weak', 'strong'])
+def test_bench_two_rank_rehearsal_over_gloo(mode):
     """The `torchrun ... bench.py --gpus N` launch path (sharded members, barrier-bracketed timing, max over
     ranks, the ensemble-mean spectrum all-reduce at snapshot time) with two ranks sharing this box's one GPU
-    and gloo in place of RCCL."""
+    and gloo in place of RCCL; weak scaling (--members per GPU) and strong scaling (--total-members: ONE ensemble
+    split into contiguous blocks whose sizes differ by at most one member: 5 + 4 of 9)."""
     import subprocess, sys
     root = os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0]
     env = dict(os.environ, QGX_BENCH_ONE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    size = ['--members', '4'] if mode == 'weak' else ['--total-members', '9']
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-           '--master-addr', '127.0.0.1', '--master-port', '29655', os.path.join(root, 'bench.py'),
-           '--gpus', '2', '--backend', 'gloo', '--steps', '260', '--warmup', '0', '--members', '4']
+           '--master-addr', '127.0.0.1', '--master-port', '29655' if mode == 'weak' else '29656', os.path.join(root, 'bench.py'),
+           '--gpus', '2', '--backend', 'gloo', '--steps', '260', '--warmup', '0'] + size
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     out = json.loads(line)
-    assert out['n_gpus'] == 2 and out['config']['total_members'] == 8 and out['scaling'] == 'weak'
+    total = 8 if mode == 'weak' else 9
+    assert out['n_gpus'] == 2 and out['config']['total_members'] == total and out['scaling'] == mode
+    assert out['config']['members_per_gpu'] == (4 if mode == 'weak' else 5)
     assert out['healthy'] and out['value'] > 0 and out['config']['cadence']['snapshots_in_timed_region'] == 1
-    assert abs(out['value'] - 8 * 260 / (out['ms_per_step'] * 260e-3)) < 1e-6 * out['value']
-    assert out['roofline']['launches_timed'] == 26 and 0 < out['roofline']['frac'] < 1      # every 10th launch is bracketed
+    assert abs(out['value'] - total * 260 / (out['ms_per_step'] * 260e-3)) < 1e-6 * out['value']
+    assert out['roofline']['launches_timed'] == 52 and 0 < out['roofline']['frac'] < 1      # every 5th launch is bracketed
+    assert 'steady' not in out and 'config4' not in out                                      # auxiliary legs: one rank only
 
 
 def test_offline_predict_returns_the_reference_dataset_layout(tmp_path):

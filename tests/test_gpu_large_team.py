@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+import conftest  # noqa: F401  (puts the repository root on sys.path; the child process of the fault test needs it)
 from oracle import qg_ref
 
 pytestmark = pytest.mark.gpu
@@ -31,11 +32,17 @@ def _engine(B, **kw):
 
 
 class _no_team:
+    """three launches per step instead of the XCD-resident run kernel, for the engines given"""
+    def __init__(self, *engines):
+        self.engines = engines
+
     def __enter__(self):
-        os.environ['QGX_LARGE_NO_TEAM'] = '1'
+        for e in self.engines:
+            e.set_option('team', 0)
 
     def __exit__(self, *a):
-        del os.environ['QGX_LARGE_NO_TEAM']
+        for e in self.engines:
+            e.set_option('team', 1)
 
 
 @pytest.mark.parametrize('B', [11, 3, 1, 9])
@@ -49,7 +56,7 @@ def test_runs_equal_the_three_launch_step_and_the_oracle(B):
     e2.set_q(q0)
     for chunk in (7, 1, 4):
         e1.step(chunk)                       # run of chunk - 1 steps + the refreshing step
-        with _no_team():
+        with _no_team(e2):
             e2.step(chunk)
         for f in (L.F_QH, L.F_DQHDT, L.F_DQHDT_PP, L.F_Q, L.F_U, L.F_V, L.F_PH):
             a, b = e1.get(f), e2.get(f)
@@ -86,7 +93,7 @@ def test_runs_respect_the_diagnostics_cadence():
         if team:
             e.step(23)
         else:
-            with _no_team():
+            with _no_team(e):
                 e.step(23)
         out.append((e.diag('KEspec').cpu().numpy(), e.diag('KEflux').cpu().numpy(), e.get(L.F_QH).cpu().numpy(),
                     e.diag_count))
@@ -121,7 +128,7 @@ def test_state_changes_between_runs_are_honoured():
     q0, q1 = _eddy_like_q(rs, B, 256), _eddy_like_q(rs, B, 256)
     e1, e2 = _engine(B, dt=3600.), _engine(B, dt=3600.)
     for e, team in ((e1, True), (e2, False)):
-        ctx = _no_team() if not team else None
+        ctx = _no_team(e) if not team else None
         if ctx:
             ctx.__enter__()
         e.set_q(q0)
@@ -148,7 +155,7 @@ def test_runs_with_other_physical_parameters(params):
     e1.set_q(q0)
     e2.set_q(q0)
     e1.step(9, refresh_diag=False)
-    with _no_team():
+    with _no_team(e2):
         e2.step(9, refresh_diag=False)
     for f in (L.F_QH, L.F_DQHDT, L.F_DQHDT_PP):
         assert _rel(e1.get(f).cpu().numpy(), e2.get(f).cpu().numpy()) < 1e-13
@@ -161,22 +168,56 @@ def test_runs_with_other_physical_parameters(params):
     e2.close()
 
 
-def test_a_flag_raised_by_the_run_kernel_surfaces_at_the_next_call():
-    """the kernel's bounded waits raise a flag instead of hanging; the next C-ABI call that touches the model reports
-    it (here raised by a test hook at the end of an otherwise complete run) and the path is switched off"""
+def test_a_flagged_run_is_undone_and_replayed_on_the_three_launch_path():
+    """the kernel's bounded waits raise a flag instead of hanging; a run is a transaction (it writes only buffers that hold
+    nothing live), so the next C-ABI call that touches the model restores the bookkeeping, switches the run kernel off and
+    replays the steps with three launches each: the run degrades, the state is never undefined.  The flag is raised by a
+    test hook that exists in the A/B library only (option 'team_fault'), hence the child process on libqgx_ab.so."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ab = os.path.join(root, 'pyqg_generative_amd', 'libqgx_ab.so')
+    if not os.path.exists(ab):
+        pytest.skip('libqgx_ab.so is not built (make -C pyqg_generative_amd/csrc ab)')
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), 'fault-child'], env=dict(os.environ, QGX_LIB=ab),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    if out.get('skip'):
+        pytest.skip(out['skip'])
+    assert out['state_before'] == 1 and out['state_after'] == -1 and out['tc'] == 12
+    assert out['err_qh'] < 1e-13 and out['err_dq'] < 1e-13 and out['err_dqpp'] < 1e-13
+    # the product library refuses the hook
     import pyqg_generative_amd._lib as L
-    e = _engine(8, dt=3600.)
-    e.set_q(_eddy_like_q(np.random.RandomState(82), 8, 256))
-    e.step(3, refresh_diag=False)
-    if e.run_kernel_state != 1:
-        pytest.skip('the census did not find 8 x 32 co-resident workgroups on this device: three-launch path only')
-    os.environ['QGX_TEAM_FAULT'] = '1'
-    try:
-        e.step(5, refresh_diag=False)              # launches asynchronously: no error yet
-        with pytest.raises(RuntimeError, match='XCD-resident step kernel raised flag'):
-            e.get(L.F_QH)
-    finally:
-        del os.environ['QGX_TEAM_FAULT']
-    e.step(4, refresh_diag=False)                  # the three-launch path from here on
-    assert e.tc == 12 and e.run_kernel_state == -1 and np.isfinite(e.get(L.F_QH).cpu().numpy()).all()
+    e = _engine(1, dt=3600.)
+    with pytest.raises(L.QgxError, match='A/B library only'):
+        e.set_option('team_fault', 1)
     e.close()
+
+
+def _fault_child():
+    import json
+    import pyqg_generative_amd._lib as L
+    B = 8
+    q0 = _eddy_like_q(np.random.RandomState(82), B, 256)
+    e, ref = _engine(B, dt=3600.), _engine(B, dt=3600.)
+    ref.set_option('team', 0)
+    for x in (e, ref):
+        x.set_q(q0)
+        x.step(3, refresh_diag=False)
+    if e.run_kernel_state != 1:
+        print(json.dumps(dict(skip='the census did not find 8 x 32 co-resident workgroups on this device: three-launch path only')))
+        return
+    before = e.run_kernel_state
+    e.set_option('team_fault', 1)
+    e.step(5, refresh_diag=False)                  # launches asynchronously; the flag is found by the next call
+    ref.step(5, refresh_diag=False)
+    e.step(4, refresh_diag=False)                  # settles (undo + replay), then three launches per step
+    ref.step(4, refresh_diag=False)
+    out = dict(state_before=before, state_after=e.run_kernel_state, tc=e.tc)
+    for key, f in (('err_qh', L.F_QH), ('err_dq', L.F_DQHDT), ('err_dqpp', L.F_DQHDT_PP)):
+        out[key] = float(_rel(e.get(f).cpu().numpy(), ref.get(f).cpu().numpy()))
+    print(json.dumps(out))
+
+
+if __name__ == '__main__' and len(__import__('sys').argv) > 1 and __import__('sys').argv[1] == 'fault-child':
+    _fault_child()

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _tool():
-    spec = importlib.util.spec_from_file_location('online_metrics', os.path.join(ROOT, 'tests', 'online_metrics_experiment.py'))
+    spec = importlib.util.spec_from_file_location('online_metrics', os.path.join(ROOT, 'tests', 'online_metrics_protocol.py'))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod

@@ -144,3 +144,45 @@ def test_spectral_subgrid_forcing_equals_the_composed_operators(N, nc):
     f = Dev.PV_subgrid_forcing(qd, N, ident, {}, 'none')[0]
     assert np.abs(f.cpu().numpy()).max() < 1e-20
     Dev.close()
+
+
+def test_plan_cache_holds_the_working_set_of_the_references_forcing_dataset_run(monkeypatch):
+    """run_forcing_datasets.py sweeps Nc = [32, 48, 64, 96, 128] x (Operator2, Operator5) with the 3/2-rule at every
+    snapshot: 15 plans / inversion models are live and the access is cyclic, so a cache smaller than that misses on
+    EVERY lookup and rebuilds engines (about 25 hipMallocs + a device-synchronising hipFree each) twice per snapshot.
+    After the first snapshot no engine may be created.  Transform plans are state-less handles (plan_only)."""
+    from pyqg_generative_amd.tools import operators as op
+    from pyqg_generative_amd import _lib
+    Dev = op.Dev
+    Dev.close()
+    created = []
+    real = op.EnsembleEngine
+
+    def counting(*a, **kw):
+        created.append((kw.get('nx'), kw.get('n_members'), bool(kw.get('plan_only'))))
+        return real(*a, **kw)
+    monkeypatch.setattr(op, 'EnsembleEngine', counting)
+    B, N = 2, 256
+    pp = {}
+    rs = np.random.RandomState(4)
+    for snap in range(3):
+        q = torch.as_tensor(rs.randn(B, 2, N, N) * 1e-6, device='cuda')
+        before = len(created)
+        hat = Dev.hires_tendency_hat(q, pp, '3/2-rule')
+        for o in (Dev.Operator2, Dev.Operator5):
+            for nc in (32, 48, 64, 96, 128):
+                Dev.subgrid_forcing_from_hat(hat[0], hat[1], nc, o, pp, '3/2-rule')
+        if snap == 0:
+            assert 10 <= len(created) <= Dev.MAX_PLANS
+        else:
+            assert len(created) == before, created[before:]
+    assert any(p for _, _, p in created) and any(not p for _, _, p in created)
+    # a plan-only handle transforms, and refuses everything that needs model state
+    plan = Dev.plan(64, 4)
+    x = torch.as_tensor(rs.randn(4, 64, 64), device='cuda')
+    _close(Dev.rfft2(x).cpu().numpy(), np.fft.rfftn(x.cpu().numpy(), axes=(-2, -1)))
+    with pytest.raises(_lib.QgxError, match='FFT plan only'):
+        plan.step(1)
+    with pytest.raises(_lib.QgxError, match='FFT plan only'):
+        plan.get(_lib.F_Q)
+    Dev.close()

@@ -324,29 +324,25 @@ def test_fused_step_noise_follows_pinned_philox_stream():
 def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B, sampling, nd):
     """Layer-split small grids: the generator's output kernel rides in the step kernel's prologue and, for white-in-time
     Philox noise, the next step's input kernel in its epilogue (GenFuse).  Same arithmetic in the same order: the run is
-    bit-identical to the one with separate kernels (QGX_NO_GENFUSE), diagnostics cadence and range words included.
+    bit-identical to the one with separate kernels (option genfuse = 0), diagnostics cadence and range words included.
     Likewise the diagnostics increment: one kernel per member against the nine launches of diag.hip."""
     import pyqg_generative_amd._lib as L
     q0 = _eddy_like_q(np.random.RandomState(7), B, N)
     gen = _gpu_generator(kind)
     res = []
     # default / separate generator kernels / nine-launch diagnostics increment
-    for env in (None, 'QGX_NO_GENFUSE', 'QGX_DIAG_UNFUSED'):
-        if env:
-            os.environ[env] = '1'
-        try:
-            e = _engine(N, B, dt=dt_for(N))
-            e.set_q(q0)
-            e.diag_config(0, 4)
-            for chunk in (7, 1, 5):
-                e.step(chunk, generator=gen, sampling=sampling, nsteps_decor=nd, seed=11, member_offset=3)
-            res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Z, L.F_Q, L.F_U, L.F_PH)] +
-                       [e.diag(n).clone() for n in ('paramspec', 'KEspec', 'KEflux', 'APEflux', 'paramspec_KEflux')] +
-                       [torch.as_tensor(gen.range_read()[1]), torch.as_tensor(e.diag_count)])
-            e.close()
-        finally:
-            if env:
-                os.environ.pop(env, None)
+    for opt in (None, 'genfuse', 'diag_fused'):
+        e = _engine(N, B, dt=dt_for(N))
+        if opt:
+            e.set_option(opt, 0)
+        e.set_q(q0)
+        e.diag_config(0, 4)
+        for chunk in (7, 1, 5):
+            e.step(chunk, generator=gen, sampling=sampling, nsteps_decor=nd, seed=11, member_offset=3)
+        res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Z, L.F_Q, L.F_U, L.F_PH)] +
+                   [e.diag(n).clone() for n in _lib_diags()] +
+                   [torch.as_tensor(gen.range_read()[1]), torch.as_tensor(e.diag_count)])
+        e.close()
     for other in res[1:]:
         for a, b in zip(res[0], other):
             assert torch.equal(a, b)
@@ -439,5 +435,32 @@ def test_randomised_configurations_match_oracle(case):
     assert gen.range_ok() is None
 
 
+def _lib_diags():
+    from pyqg_generative_amd._lib import DIAGS
+    return DIAGS
+
+
 def dt_for(N):
     return 14400. if N <= 64 else 7200.
+
+
+@pytest.mark.parametrize('N', [64, 256])
+def test_fields_after_unrefreshed_steps_belong_to_the_current_state(N):
+    """steps with refresh_diag=False store no ph, u, v (every step of a 256 x 256 run kernel): reading u, v, ph or p
+    afterwards inverts the CURRENT state first instead of handing out fields of an older one"""
+    import pyqg_generative_amd._lib as L
+    B = 2
+    q0 = _eddy_like_q(np.random.RandomState(21), B, N)
+    e = _engine(N, B, dt=3600.)
+    e.set_q(q0)
+    e.step(2)                                  # refreshed: fields of the inversion of step 2
+    e.step(7, refresh_diag=False)
+    u, p = e.get(L.F_U).cpu().numpy(), e.get(L.F_P).cpu().numpy()
+    for b in range(B):
+        m = qg_ref.QGModelRef(nx=N, dt=3600.)
+        m.set_q(q0[b])
+        for _ in range(9):
+            m._step_forward()
+        m._invert()                            # of the state after step 9
+        assert _rel(u[b], m.u) < 1e-10
+        assert _rel(p[b], m.ifft(m.ph)) < 1e-10

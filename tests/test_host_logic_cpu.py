@@ -95,3 +95,37 @@ def test_shard_members_partitions_every_member_once():
     assert shard_members(1024, 3, 8) == (384, 128)
     with pytest.raises(ValueError):
         shard_members(8, 8, 8)
+
+
+def test_product_set_initial_condition_matches_reference_golden():
+    """the product's own set_initial_condition (host numpy, tools/simulate.py) against the reference's output for the
+    same global numpy seed (tests/golden/make_golden.py G7: np.random.seed(N), duck-typed model) — directly, not through
+    a trajectory; and the per-member seeded form draws the same numbers from RandomState(seed)."""
+    from pyqg_generative_amd.tools.simulate import set_initial_condition
+    g = golden('initial_condition.npz')
+
+    class _M:
+        inverted = 0
+
+        def _invert(self):
+            self.inverted += 1
+    for N in (48, 64, 96):
+        m = _M()
+        m.nx = m.ny = N
+        m.L = 1e6
+        dk = 2 * np.pi / m.L
+        ll = dk * np.append(np.arange(0., N / 2), np.arange(-N / 2, 0.))
+        kk = dk * np.arange(0., N // 2 + 1)
+        kx, ly = np.meshgrid(kk, ll)
+        m.wv = np.sqrt(kx ** 2 + ly ** 2)
+        np.random.seed(N)
+        set_initial_condition(m)                     # seeds=None: numpy's global stream, the reference's draw order
+        assert m.q.shape == (2, N, N) and m.inverted == 1
+        np.testing.assert_allclose(m.q[0], g[f'q1_{N}'], rtol=0, atol=1e-22)
+        assert np.abs(m.q[1]).max() == 0
+        m2 = _M()
+        m2.__dict__.update(nx=N, ny=N, L=m.L, wv=m.wv, n_members=3)
+        set_initial_condition(m2, seeds=[7, N, 9])   # member 1 draws from RandomState(N): the same field
+        assert m2.q.shape == (3, 2, N, N)
+        np.testing.assert_allclose(m2.q[1, 0], g[f'q1_{N}'], rtol=0, atol=1e-22)
+        assert np.abs(m2.q[0, 0] - m2.q[1, 0]).max() > 1e-9

@@ -173,6 +173,62 @@ def test_energy_budget_of_the_diagnostics_closes():
         np.testing.assert_allclose([_hermitian_sum(d['Ensspec'][z]) for z in (0, 1)], (m.q ** 2).mean(axis=(1, 2)), rtol=1e-10)
 
 
+def test_enstrophy_budget_and_filter_dissipation_of_the_diagnostics_close():
+    """The barotropic-enstrophy diagnostics are a decomposition of the tendency of Z = 1/2 sum_k (H_k/H) |qh_k|^2 / M^2
+    WAVENUMBER BY WAVENUMBER: Re[sum_k H_k/H conj(qh_k) dqh_k/dt] / M^2 == ENSflux + ENSgenspec + ENSfrictionspec +
+    ENSparamspec for the tendency the model steps with.  The nonlinear flux only redistributes (sum(ENSflux) = 0 once the
+    cubic products are alias-free), bottom drag and the filter only remove: ENSDissspec <= 0 everywhere, and over a real
+    time step the change of Z and of the energy E equals (budget terms) + the filter's share, i.e. what is left of
+    Z^{n+1} - Z^n after the unfiltered AB update is exactly dt * ENSDissspec + the quadratic remainder
+    |diss|^2 / 2 (an identity of the update, checked to round-off)."""
+    N = 64
+    rs = np.random.RandomState(6)
+    S = rs.randn(2, N, N) * np.array([7e-12, 2e-13])[:, None, None]
+    for band, params in ((1. / 4., {}), (0.95, dict(rek=7e-8, delta=0.1, beta=1e-11))):
+        m = qg_ref.QGModelRef(nx=N, dt=14400., parameterization=lambda mm: S, **params)
+        q = rs.randn(2, N, N) * np.array([8e-6, 1e-6])[:, None, None]
+        m.set_qh(np.fft.rfftn(q, axes=(-2, -1)) * (m.wv < band * m.kk[-1]))
+        if band <= 0.25:                       # alias-free cubic products: the enstrophy flux sums to zero
+            m._invert()
+            m._do_advection()
+            f0 = m._diag_functions()['ENSflux']
+            assert abs(_hermitian_sum(f0)) < 1e-12 * _hermitian_sum(np.abs(f0))
+        for _ in range(3):                     # AB3 history in place (dqhdt_p, dqhdt_pp non-zero, ablevel 2)
+            m._step_forward()
+        m._invert()
+        m._do_advection()
+        m._do_friction()
+        m._do_q_subgrid_parameterization()
+        d = m._diag_functions()
+        hr = (m.Hi / m.H)[:, None, None]
+        dZdt = (hr * np.real(np.conj(m.qh) * m.dqhdt)).sum(0) / m.M ** 2
+        total = d['ENSflux'] + d['ENSgenspec'] + d['ENSfrictionspec'] + d['ENSparamspec']
+        scale = sum(np.abs(d[k]).max() for k in ('ENSflux', 'ENSgenspec', 'ENSfrictionspec', 'ENSparamspec'))
+        np.testing.assert_allclose(total, dZdt, rtol=0, atol=1e-12 * scale)
+        # the filter: unfiltered update u = qh + sum dt_i T_i, filtered qh' = f u, diss = (f - 1) u
+        dt1, dt2, dt3 = 23. / 12. * m.dt, -16. / 12. * m.dt, 5. / 12. * m.dt
+        unf = m.qh + dt1 * m.dqhdt + dt2 * m.dqhdt_p + dt3 * m.dqhdt_pp
+        diss = (m.filtr - 1.0) * unf
+        np.testing.assert_allclose(diss, m._dissipation_spectrum(), rtol=0, atol=0)
+        assert (m.filtr <= 1.0).all()
+        if band > 0.9:
+            assert np.abs(diss).max() > 0
+        # ENSDissspec * dt == Re[sum hr conj(qh) diss] / M^2; against the filtered state of a real step:
+        # Z(f u) - Z(u) = Re[sum hr conj(u) diss] + |diss|^2/2 (per wavenumber), and conj(u) = conj(qh) + O(dt)
+        qh_n, ph_n = m.qh.copy(), m.ph.copy()
+        np.testing.assert_allclose(d['ENSDissspec'] * m.dt, (hr * np.real(np.conj(qh_n) * diss)).sum(0) / m.M ** 2,
+                                   rtol=0, atol=1e-13 * max(np.abs(d['ENSDissspec']).max() * m.dt, 1e-300))
+        np.testing.assert_allclose(d['Dissspec'] * m.dt, -(hr * np.real(np.conj(ph_n) * diss)).sum(0) / m.M ** 2,
+                                   rtol=0, atol=1e-13 * max(np.abs(d['Dissspec']).max() * m.dt, 1e-300))
+        m._forward_timestep()
+        np.testing.assert_allclose(m.qh, m.filtr * unf, rtol=0, atol=1e-15 * np.abs(unf).max())
+        Zf = 0.5 * (hr * np.abs(m.filtr * unf) ** 2).sum(0)
+        Zu = 0.5 * (hr * np.abs(unf) ** 2).sum(0)
+        ident = (hr * (np.real(np.conj(unf) * diss) + 0.5 * np.abs(diss) ** 2)).sum(0)
+        np.testing.assert_allclose(Zf - Zu, ident, rtol=0, atol=1e-12 * np.abs(Zu).max())
+        assert (Zf <= Zu).all()                                                # the filter only removes enstrophy
+
+
 def test_published_48x48_log_is_reproduced():
     """Google-Colab/online-simulations.ipynb:318-347 (48 x 48, dt = 7200 s): CFL 0.009 while the flow is at
     rest, KE growing by x2.8-2.9 per 1000 steps late in the linear stage (the printed run carries the GAN
