@@ -141,6 +141,7 @@ int qgx_reset_time(qgx_model *m);
 /* Kernel-path switches of a model (no reference counterpart; cross-checks in tests/, A/B timing in bench_tools/):
  * every setting computes the same step, only the fusion / tiling differs.  "genfuse" (0|1: generator output and
  * next-input kernels folded into the small-grid step kernel), "diag_fused" (0|1: one-kernel diagnostics increment),
+ * "diag_wide" (-1 auto|0|1: its transforms as (member, transform) workgroups),
  * "lsplit" (-1 auto|0|1: one workgroup per member and layer), "spec_threads" (0 auto|256|512|1024), "team" (0|1:
  * XCD-resident runs at 256 x 256), "team_min" (shortest such run), "large_fused", "large_lazy_q",
  * "large_specialised" (0|1: the large-grid kernel variants).  The library reads NO environment variable. */

@@ -47,7 +47,9 @@ constexpr int MAX_RADIX_PASSES = 12;
 // (cross-checks in tests/, A/B timing in bench_tools/); none changes what is computed beyond rounding order.
 struct ModelOpts {
     int genfuse = 1;             // small grids: generator output / next-input kernels folded into the step kernel
-    int diag_fused = 1;          // small grids: one-kernel diagnostics increment (0: the nine launches of diag.hip)
+    int diag_fused = 1;          // small grids: one-kernel diagnostics increment (0: one launch per transform, diag.hip)
+    int diag_wide = -1;          // small grids: the increment's transforms as (member, transform) workgroups, 3 launches
+                                 //   (-1: while 6 B <= 256 | 0 | 1)
     int lsplit = -1;             // small grids: two workgroups per member, one per layer (-1 auto | 0 | 1)
     int spec_threads = 0;        // small grids: threads of the one-workgroup-per-member kernels (0 auto | 256 | 512 | 1024)
     int team = 1;                // 256 x 256: XCD-resident runs of unparameterized steps

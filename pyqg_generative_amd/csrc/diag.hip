@@ -22,6 +22,10 @@ int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh
                          double weight, const double *q, const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st);
 
 
+int small_diag_transforms_wide(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
+                               double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, double2 *S6, double2 *S7, const double *S,
+                               double weight, const double *q, hipStream_t st);
+
 // xih_k = -wv2 * ph_k
 __global__ void k_diag_xih(SpecDev d, const double2 *ph, double2 *xih) {
     const int sz = d.N * d.NK, b = blockIdx.y;
@@ -116,9 +120,22 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
     a.paramspec_APEflux = m->dg_acc[8]; a.paramspec_KEflux = m->dg_acc[9];
     a.Dissspec = m->dg_acc[10]; a.ENSDissspec = m->dg_acc[11]; a.ENSflux = m->dg_acc[12]; a.ENSgenspec = m->dg_acc[13];
     a.ENSfrictionspec = m->dg_acc[14]; a.ENSparamspec = m->dg_acc[15];
+    if (m->small && m->opts.diag_fused && (m->opts.diag_wide > 0 || (m->opts.diag_wide < 0 && 6 * d.B <= 256))) {
+        // few members: the ten transforms as (member, transform) workgroups — two launches — then the accumulation kernel;
+        // a single member's increment is three short kernels instead of a chain of ten transforms on one CU
+        rc = small_diag_transforms_wide(d, c, qh, m->ph, m->u, m->v, p, xi, S3, S4, S5, Sh, S6, S7, S, weight, m->q, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_diag_accumulate, dgrid(d, d.N * d.NK), dim3(256), 0, st, d, c, (const double2 *)qh,
+                           (const double2 *)m->ph, (const double2 *)S3, (const double2 *)S4, (const double2 *)S5,
+                           S ? (const double2 *)Sh : (const double2 *)nullptr, (const double2 *)S6, (const double2 *)S7, dq_p, dq_pp, a);
+        QGX_HIP(hipGetLastError());
+        m->uv_stale = false;
+        m->dg_count += 1;
+        return QGX_OK;
+    }
     if (m->small && m->opts.diag_fused) {
-        // small grids: the whole increment (inversion, eight packed transforms, products, accumulation) in ONE kernel, a
-        // workgroup per member (spectral_small.hip::k_diag_small) instead of nine launches
+        // small grids: the whole increment (inversion, ten packed transforms, products, accumulation) in ONE kernel, a
+        // workgroup per member (spectral_small.hip::k_diag_small) instead of a dozen launches
         rc = small_diag_increment(d, c, qh, m->ph, m->u, m->v, p, xi, S3, S4, S5, Sh, S6, S7, S, weight, m->q, dq_p, dq_pp, a, st);
         if (rc) return rc;
         m->uv_stale = false;

@@ -407,6 +407,7 @@ extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
     ModelOpts &o = m->opts;
     if (!strcmp(name, "genfuse")) o.genfuse = value ? 1 : 0;
     else if (!strcmp(name, "diag_fused")) o.diag_fused = value ? 1 : 0;
+    else if (!strcmp(name, "diag_wide")) { QGX_REQUIRE(value >= -1 && value <= 1, "diag_wide must be -1 (auto), 0 or 1"); o.diag_wide = value; }
     else if (!strcmp(name, "lsplit")) { QGX_REQUIRE(value >= -1 && value <= 1, "lsplit must be -1 (auto), 0 or 1"); o.lsplit = value; }
     else if (!strcmp(name, "spec_threads")) {
         QGX_REQUIRE(value == 0 || value == 256 || value == 512 || value == 1024, "spec_threads must be 0 (auto), 256, 512 or 1024");

@@ -485,6 +485,115 @@ __global__ void k_diag_small(SpecDev d, DiagConst c, const double2 *qh, double2 
     }
 }
 
+// ------------------------------------------------------------------ the same increment spread over several workgroups per member
+// One workgroup per member is a chain of ten dependent 2-D transforms on ONE CU (about 110 us for a single member, and half
+// of the CUs idle at 128).  The four inverse transforms depend on qh alone and the six forward transforms on their results
+// alone, so they are run as two launches of (member, transform) workgroups followed by diag.hip's accumulation kernel:
+// three short launches instead of one long one.  Same device functions, same expressions: bit-identical to k_diag_small.
+//   which 0, 1: _invert of layer k -> ph_k, u_k, v_k;  2: p = irfft2(psi) (both layers packed);  3: xi = irfft2(-K^2 psi)
+template <int NN>
+__global__ void k_diag_inv_small(SpecDev d, const double2 *qh, double2 *ph, double *u, double *v, double *P, double *XI,
+                                 double2 *T3, double2 *T4) {
+    double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
+    int *pos_lds;
+    Grid g = make_grid(d, Z, pos_lds);
+    if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
+    const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD;
+    const int b = blockIdx.x >> 2, which = blockIdx.x & 3;
+    const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
+    const int sz = N * NK, rz = N * N;
+    __syncthreads();
+    if (which < 2) {
+        const int k = which;
+        build_uv(Z, g, d, k, qh + so, qh + so + sz, ph + so + k * sz);
+        __syncthreads();
+        fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+        for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+            const int y = idx / N, x = idx - y * N;
+            const double2 uv = Z[y * LD + x];
+            u[ro + k * rz + idx] = uv.x;
+            v[ro + k * rz + idx] = uv.y;
+        }
+        return;
+    }
+    // psi (which == 2) or -K^2 psi (which == 3) of both layers into this workgroup's own scratch, then one packed pair
+    double2 *T = which == 2 ? T4 : T3;
+    for (int idx = threadIdx.x; idx < 2 * sz; idx += blockDim.x) {
+        const int k = idx / sz, r = idx - k * sz;
+        const double2 p = invert_layer(d, k, r, qh[so + r], qh[so + sz + r]);
+        if (which == 2) T[so + idx] = p;
+        else {
+            const double w = -d.wv2[r];
+            T[so + idx] = make_double2(w * p.x, w * p.y);
+        }
+    }
+    __syncthreads();
+    build_pair(Z, g, T + so, T + so + sz, d.invN2);
+    __syncthreads();
+    fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    double *dst = which == 2 ? P : XI;
+    for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+        const int y = idx / N, x = idx - y * N;
+        const double2 w = Z[y * LD + x];
+        dst[ro + idx] = w.x;
+        dst[ro + rz + idx] = w.y;
+    }
+}
+
+// which 0..5: the product pair (or the forcing, which == 3) of k_diag_small, transformed and unpacked into its spectrum array
+template <int NN>
+__global__ void k_diag_fwd_small(SpecDev d, DiagConst c, const double *u, const double *v, const double *P, const double *XI,
+                                 const double *q, const double *S, double weight, double2 *S3, double2 *S4, double2 *S5, double2 *Sh,
+                                 double2 *S6, double2 *S7, int nwhich) {
+    double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
+    int *pos_lds;
+    Grid g = make_grid(d, Z, pos_lds);
+    if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
+    const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD;
+    const int b = blockIdx.x / nwhich;
+    int which = blockIdx.x - b * nwhich;
+    if (!S && which >= 3) ++which;                 // no forcing: five pairs, the slot of the forcing is skipped
+    const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
+    const int sz = N * NK, rz = N * N;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+        const int y = idx / N, x = idx - y * N;
+        const size_t o = ro + idx;
+        double ra, rb;
+        if (which == 0) {
+            const double u1 = u[o], u2 = u[o + rz], v1 = v[o], v2 = v[o + rz];
+            const double ptpc = P[o] - P[o + rz];
+            const double ub = c.del1 * u1 + c.del2 * u2, vb = c.del1 * v1 + c.del2 * v2;
+            ra = ub * ptpc; rb = vb * ptpc;
+        } else if (which == 1) {
+            const double x1 = XI[o];
+            ra = u[o] * x1; rb = v[o] * x1;
+        } else if (which == 2) {
+            const double x2 = XI[o + rz];
+            ra = u[o + rz] * x2; rb = v[o + rz] * x2;
+        } else if (which == 3) {
+            ra = weight * S[o]; rb = weight * S[o + rz];
+        } else if (which == 4) {
+            const double q1 = q[o];
+            ra = u[o] * q1; rb = v[o] * q1;
+        } else {
+            const double q2 = q[o + rz];
+            ra = u[o + rz] * q2; rb = v[o + rz] * q2;
+        }
+        Z[y * LD + x] = make_double2(ra, rb);
+    }
+    __syncthreads();
+    fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    double2 *dst = which == 0 ? S3 : (which == 1 ? S4 : (which == 2 ? S5 : (which == 3 ? Sh : (which == 4 ? S6 : S7))));
+    for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
+        const int j = idx / NK, i = idx - j * NK;
+        double2 s0, s1;
+        unpack_pair(Z, g, j, i, s0, s1);
+        dst[so + idx] = s0;
+        dst[so + sz + idx] = s1;
+    }
+}
+
 // ------------------------------------------------------------------ host launchers
 static size_t small_lds_bytes(const SpecDev &d) {
     size_t bytes = (size_t)d.N * d.LD * sizeof(double2) + (size_t)((d.N + 3) & ~3) * sizeof(int) + (size_t)d.N * sizeof(double2);
@@ -524,6 +633,8 @@ int small_prepare(const SpecDev &d) {
         QGX_HIP(hipFuncSetAttribute((const void *)k_qh_to_q_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_diag_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        QGX_HIP(hipFuncSetAttribute((const void *)k_diag_inv_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        QGX_HIP(hipFuncSetAttribute((const void *)k_diag_fwd_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     })
     return QGX_OK;
 }
@@ -563,6 +674,19 @@ int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh
                          double weight, const double *q, const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st) {
     QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_diag_small<NN>, dim3(d.B), dim3(1024), small_lds_bytes(d), st, d, c, qh, ph, u, v, P, XI,
                                            S3, S4, S5, Sh, S6, S7, S, weight, q, dq_p, dq_pp, a))
+    QGX_HIP(hipGetLastError());
+    return QGX_OK;
+}
+// the transforms of one increment as (member, transform) workgroups: inverse set, then forward set (k_diag_accumulate follows)
+int small_diag_transforms_wide(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
+                               double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, double2 *S6, double2 *S7, const double *S,
+                               double weight, const double *q, hipStream_t st) {
+    const int nwhich = S ? 6 : 5;
+    QGX_DISPATCH_N(d.N, {
+        hipLaunchKernelGGL(k_diag_inv_small<NN>, dim3(4 * d.B), dim3(1024), small_lds_bytes(d), st, d, qh, ph, u, v, P, XI, S3, S4);
+        hipLaunchKernelGGL(k_diag_fwd_small<NN>, dim3(nwhich * d.B), dim3(1024), small_lds_bytes(d), st, d, c, (const double *)u,
+                           (const double *)v, (const double *)P, (const double *)XI, q, S, weight, S3, S4, S5, Sh, S6, S7, nwhich);
+    })
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }

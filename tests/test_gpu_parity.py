@@ -325,16 +325,18 @@ def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B
     """Layer-split small grids: the generator's output kernel rides in the step kernel's prologue and, for white-in-time
     Philox noise, the next step's input kernel in its epilogue (GenFuse).  Same arithmetic in the same order: the run is
     bit-identical to the one with separate kernels (option genfuse = 0), diagnostics cadence and range words included.
-    Likewise the diagnostics increment: one kernel per member against the nine launches of diag.hip."""
+    Likewise the diagnostics increment: one kernel per member, its transforms spread over (member, transform) workgroups, or
+    one launch per transform (diag.hip) — all sixteen accumulated diagnostics bit for bit."""
     import pyqg_generative_amd._lib as L
     q0 = _eddy_like_q(np.random.RandomState(7), B, N)
     gen = _gpu_generator(kind)
     res = []
-    # default / separate generator kernels / nine-launch diagnostics increment
-    for opt in (None, 'genfuse', 'diag_fused'):
+    # default / separate generator kernels / one launch per transform / the increment's transforms as (member, transform)
+    # workgroups (three launches) / as ONE workgroup per member
+    for opt, val in ((None, 0), ('genfuse', 0), ('diag_fused', 0), ('diag_wide', 1), ('diag_wide', 0)):
         e = _engine(N, B, dt=dt_for(N))
         if opt:
-            e.set_option(opt, 0)
+            e.set_option(opt, val)
         e.set_q(q0)
         e.diag_config(0, 4)
         for chunk in (7, 1, 5):
