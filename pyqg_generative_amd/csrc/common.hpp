@@ -183,6 +183,7 @@ struct qgx_model {
     double *dg_R[7] = {};
     double *dg_S[7] = {};
     double *dg_acc[qgx::N_DIAGS] = {};
+    double2 *dg_z = nullptr;               // large grids: the four work fields of the three-launch increment (spectral_large.hip)
 };
 
 namespace qgx {

@@ -19,6 +19,7 @@
 // Lane half h consumes K indices 8g+4h .. 8g+4h+3 of every group of 8 with one 16-byte
 // read of A (LDS) and of B (packed weights, L2 resident) feeding 4 consecutive MFMAs.
 #include "common.hpp"
+#include <unordered_map>
 #include "philox.hpp"
 #include <cmath>
 #include <utility>
@@ -843,6 +844,21 @@ struct qgx_generator {
 
 namespace qgx {
 
+// hipFuncSetAttribute takes microseconds of host time; the single-member step is a chain of 5-15 us kernels whose
+// launches the host has to keep ahead of: the dynamic-LDS cap of a kernel is raised once per kernel, device and host
+// thread, not once per launch (rocprofv3: 14 launches / 116 us of kernels per step were taking 128 us of wall time)
+static int ensure_dynamic_lds(const void *kern, int bytes) {
+    static thread_local std::unordered_map<const void *, int> seen[16];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto &m = seen[dev & 15];
+    const auto it = m.find(kern);
+    if (it != m.end() && it->second >= bytes) return QGX_OK;
+    QGX_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    m[kern] = bytes;
+    return QGX_OK;
+}
+
 static const int KSZ[8] = {5, 5, 3, 3, 3, 3, 3, 3};
 static const int HID[7] = {128, 64, 32, 32, 32, 32, 32};
 
@@ -1090,11 +1106,11 @@ static int launch_conv(qgx_generator *g, int layer, const LayerHost &L, const fl
     dim3 grid(B * (N / R), CSPLIT), block(256);
     if (ntiles <= 8) {
         auto kern = k_conv<CIN, COUT, KS, CC, 2, PLANAR_IN, FINAL, CSPLIT, false, OUTH>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     } else {
         auto kern = k_conv<CIN, COUT, KS, CC, 3, PLANAR_IN, FINAL, CSPLIT, false, OUTH>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     }
     QGX_HIP(hipGetLastError());
@@ -1140,7 +1156,7 @@ static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, co
     dim3 grid(B * (N / R), nsplit), block(256);
     if (nsplit > 1) {
         auto kern = k_conv<CIN, COUT, KS, CC, 1, false, false, 1, true>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
         const size_t n4 = npix * COUT / 4;
         hipLaunchKernelGGL(k_conv_reduce<COUT>, dim3((unsigned)((n4 + 255) / 256 > 1024 ? 1024 : (n4 + 255) / 256)), dim3(256),
@@ -1148,7 +1164,7 @@ static int launch_conv_small(qgx_generator *g, int layer, const LayerHost &L, co
                            (const float *)L.shift, out);
     } else {
         auto kern = k_conv<CIN, COUT, KS, CC, 1, false, false, 1, false>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);
     }
     QGX_HIP(hipGetLastError());
@@ -1185,7 +1201,7 @@ static int launch_conv3(qgx_generator *g, int layer, const LayerHost &L, const f
 #define QGX_L3(MTV, PPTV)                                                                                     \
     {                                                                                                         \
         auto kern = k_conv3<CIN, COUT, KS, CC, MTV, TPS, PPTV, NW>;                                           \
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; } \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);                         \
     }
     const int mtv = (ntiles + NW - 1) / NW <= 1 ? 1 : ((ntiles + NW - 1) / NW == 2 ? 2 : 3);
@@ -1252,11 +1268,11 @@ static int launch_conv_last(qgx_generator *g, const LayerHost &L, const float *i
     QGX_REQUIRE(lds <= 160 * 1024, "generator: LDS patch %zu B too large for N=%d", lds, N);
     if (split) {
         auto kern = k_conv_last<32, 3, 4>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
         hipLaunchKernelGGL(kern, dim3(B * (N / R)), dim3(256), lds, st, a, L.wv_host);
     } else {
         auto kern = k_conv_last<32, 3>;
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
         hipLaunchKernelGGL(kern, dim3(B * (N / R)), dim3(256), lds, st, a, L.wv_host);
     }
     QGX_HIP(hipGetLastError());
@@ -1332,7 +1348,7 @@ static int launch_convh(qgx_generator *g, int layer, const LayerHost &L, const v
 #define QGX_LH(MTV, PPTV, NWV, SWZV)                                                                          \
     {                                                                                                         \
         auto kern = k_convh<CIN, COUT, KS, NS, MTV, TPS, PPTV, OUTF32, NWV, SWZV>;                            \
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; } \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, a, total_tiles);                        \
     }
     if (four) {
@@ -1380,7 +1396,7 @@ static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, cons
     constexpr bool TWO = lds * 2 <= 160 * 1024 && MT == 2;        // two workgroups per CU: <= 256 registers
     auto kern = g->opt_pair && KS == 3 ? k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO, KS == 3>
                                         : k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO, false>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
@@ -1414,7 +1430,7 @@ static int launch_convh2_part_n(qgx_generator *g, int layer, const LayerHost &L,
     const int total_tiles = B * (NN / R);
     constexpr bool TWO = lds * 2 <= 160 * 1024 && MT == 2;
     auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, WDB, TWO, false, true>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(total_tiles, nsplit), dim3(256), lds, st, a, total_tiles);
     const size_t n = npix * (COUT / 8);
     hipLaunchKernelGGL((k_convh_reduce<COUT, OUTF32>), dim3((unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, st,
@@ -1459,7 +1475,7 @@ static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, con
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
     auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, false, true, false, false, false, NW, TW>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
@@ -1484,7 +1500,7 @@ static int launch_convh2_w8_3x3(qgx_generator *g, int layer, const LayerHost &L,
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
     auto kern = k_convh2<CIN, COUT, KS, NN, MT, TPS, OUTF32, true, false, true, false, NW, TW>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
@@ -1548,7 +1564,7 @@ static int launch_convh_res(qgx_generator *g, int layer, const LayerHost &L, con
 #define QGX_LR(MTV, PPTV)                                                                                     \
     {                                                                                                         \
         auto kern = k_convh_res<CIN, COUT, MTV, PPTV, OUTF32>;                                                \
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; } \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);                             \
     }
     if (mtv == 2) { if (ppt <= 10) QGX_LR(2, 10) else QGX_LR(2, 14) }
@@ -1602,7 +1618,7 @@ static int launch_convh3(qgx_generator *g, int layer, const LayerHost &L, const 
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
     auto kern = k_convh3<NN>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
@@ -1627,7 +1643,7 @@ static int launch_convh4_n(qgx_generator *g, int layer, const LayerHost &L, cons
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
     auto kern = k_convh4<NN, MT, NW>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
@@ -1667,7 +1683,7 @@ static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, 
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
     auto kern = k_convh_pair<CINA, NN, LAST, BOUTF32>;
-    QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
@@ -1705,7 +1721,7 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
 #define QGX_LF(MTV, PPTV, NWV)                                                                                \
     {                                                                                                         \
         auto kern = k_convh_first<NIN, MTV, PPTV, NWV>;                                                       \
-        QGX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; } \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, a, total_tiles);                        \
     }
     if (w8) { if (ppt <= 2) QGX_LF(2, 2, 8) else QGX_LF(2, 3, 8) }

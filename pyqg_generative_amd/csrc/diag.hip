@@ -17,6 +17,9 @@ int large_q_to_qh(qgx_model *m, const double *q, double2 *qh, hipStream_t st);
 int large_qh_to_q(qgx_model *m, const double2 *qh, double *q, hipStream_t st);
 int large_invert(qgx_model *m, hipStream_t st);
 int large_ensure_q(qgx_model *m, hipStream_t st);
+bool large_diag_fused_ok(const qgx_model *m);
+int large_diag_fused(qgx_model *m, const DiagConst &c, const double2 *qh, const double2 *Sh, const double2 *dq_p, const double2 *dq_pp,
+                     const DiagAcc &acc, hipStream_t st);
 int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
                          double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, double2 *S6, double2 *S7, const double *S,
                          double weight, const double *q, const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st);
@@ -139,6 +142,19 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
         rc = small_diag_increment(d, c, qh, m->ph, m->u, m->v, p, xi, S3, S4, S5, Sh, S6, S7, S, weight, m->q, dq_p, dq_pp, a, st);
         if (rc) return rc;
         m->uv_stale = false;
+        m->dg_count += 1;
+        return QGX_OK;
+    }
+    if (!m->small && large_diag_fused_ok(m)) {
+        // large grids at the specialised sizes: the increment's four packed fields through three fused launches
+        // (spectral_large.hip); ph is stored, u and v are not (uv_stale stays as it is: they are inverted on demand)
+        const double2 *Shp = nullptr;
+        if (S) {
+            hipLaunchKernelGGL(k_diag_scale_S, dim3(1024), dim3(256), 0, st, S, R3, nr, weight);
+            if ((rc = large_q_to_qh(m, R3, Sh, st))) return rc;
+            Shp = Sh;
+        }
+        if ((rc = large_diag_fused(m, c, qh, Shp, dq_p, dq_pp, a, st))) return rc;
         m->dg_count += 1;
         return QGX_OK;
     }

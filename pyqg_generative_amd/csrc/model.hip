@@ -303,7 +303,7 @@ extern "C" int qgx_destroy(qgx_model *m) {
     if (!m) return QGX_OK;
     (void)hipSetDevice(m->cfg.device);
     void *ptrs[] = {m->t_filtr, m->t_wv2, m->t_a, m->t_kk, m->t_ll, m->t_tw, m->t_pos, m->q, m->u, m->v,
-                    m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->dq[3], m->zbuf, m->team_ctl,
+                    m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->dq[3], m->dg_z, m->zbuf, m->team_ctl,
                     m->z, m->xi, m->dg_R[0], m->dg_R[1], m->dg_R[2], m->dg_R[3], m->dg_R[4], m->dg_S[0], m->dg_S[1],
                     m->dg_S[2], m->dg_S[3], m->dg_S[4], m->dg_acc[0], m->dg_acc[1], m->dg_acc[2], m->dg_acc[3],
                     m->dg_acc[4], m->dg_acc[5], m->dg_acc[6], m->dg_acc[7], m->dg_acc[8], m->dg_acc[9]};

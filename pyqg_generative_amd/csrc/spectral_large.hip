@@ -10,6 +10,7 @@
 // pyqg_generative/tools/simulate.py:83-88 — the 256^2 forcing-dataset runs).
 #include "common.hpp"
 #include "fft_lds.hpp"
+#include "diag_acc.hpp"
 #include <cstdlib>
 
 namespace qgx {
@@ -504,6 +505,173 @@ __global__ __launch_bounds__(NT > 0 ? NT : 1024) void k_l_rows_fwd_tend(SpecDev 
     }
 }
 
+// ================================================================================================
+// One increment of the time-averaged diagnostics on the large grids in THREE launches (model.py::_calc_diagnostics).
+// Composed from the generic transforms (diag.hip) an increment at 256 x 256 is ~30 launches and 4.9 GB of traffic per
+// 64 members: eight packed 2-D transforms, each a row kernel + a column kernel + a pack / unpack sweep, with the
+// real-space fields written and re-read in between.  Here the FOUR packed fields an increment needs ride through the
+// row / column kernels together, as (u, v, q) do in the unparameterized step:
+//   rows:    from qh: spectra of (u_1 + i v_1), (u_2 + i v_2), (q_1 + i q_2), (p_1 + i p_2), inverse along x; psi stored
+//   columns: inverse along y, the four product pairs, forward along y
+//              (u_1 q_1, v_1 q_1), (u_2 q_2, v_2 q_2), (u_1 d, v_1 d), (u_2 d, v_2 d),  d = p_1 - p_2
+//   rows:    forward along x, unpack, accumulate the sixteen diagnostics (diag_acc.hpp)
+// The relative vorticity xi_k = irfft2(-K^2 psi_k) is not transformed: q_1 = xi_1 + F_1 (p_2 - p_1),
+// q_2 = xi_2 + F_2 (p_1 - p_2), so u_k xi_k = u_k q_k +/- F_k u_k d, and the thickness-weighted products of APEflux are
+// del_1 (u_1 d) + del_2 (u_2 d): four forward transforms carry the five product pairs of the composed form (rounding
+// differs at 1e-14 relative: cancellation by at most 1 + F / K_min^2 ~ 90).
+// ================================================================================================
+constexpr int DZF = 4;       // complex work fields per member of the fused increment
+
+template <int NN, int PPWT, int NT>
+__global__ __launch_bounds__(NT) void k_l_rows_diag_inv(SpecDev d, const double2 *src, double2 *dz, double2 *ph_out, int ZP) {
+    constexpr int NF = DZF, N = NN, NK = N / 2 + 1, LD = N + 1, sz = N * NK, PPW = PPWT, nlines = PPW * 2 * NF;
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    int *pos = reinterpret_cast<int *>(L + (size_t)nlines * LD);
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));
+    for (int t = threadIdx.x; t < N; t += NT) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
+    constexpr int groups = (N / 2) / PPW;
+    const int b = blockIdx.x / groups, p0 = (blockIdx.x - b * groups) * PPW;
+    const double2 *s0 = src + (size_t)b * 2 * sz, *s1 = s0 + sz;
+    __syncthreads();
+#pragma unroll
+    for (int t = threadIdx.x; t < PPW * 2 * NK; t += NT) {
+        const int i = t % NK, r = t / NK;
+        const int j = pair_row(p0 + (r >> 1), r & 1, N), jm = neg_mod_l(j, N);
+        const int rm = (p0 + (r >> 1)) == 0 ? r : (r ^ 1);
+        const int idx = j * NK + i, idm = jm * NK + i;
+        const bool selfc = (i == 0 || 2 * i == N);
+        const double2 q0 = s0[idx], q1 = s1[idx];
+        double2 q0m = q0, q1m = q1;
+        if (selfc) { q0m = s0[idm]; q1m = s1[idm]; }
+        const double kx = d.kk[i], ly = d.ll[j], lm = d.ll[jm];
+        double2 phk[2], phm[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double2 ph = invert_l(d, k, idx, q0, q1);
+            phk[k] = ph; phm[k] = ph;
+            ph_out[(size_t)b * 2 * sz + k * sz + idx] = ph;
+            double2 uh = make_double2(ly * ph.y, -ly * ph.x);
+            double2 vh = make_double2(-kx * ph.y, kx * ph.x);
+            if (selfc) {
+                const double2 pm = invert_l(d, k, idm, q0m, q1m);
+                phm[k] = pm;
+                const double2 um = make_double2(lm * pm.y, -lm * pm.x);
+                const double2 vm = make_double2(-kx * pm.y, kx * pm.x);
+                uh = make_double2(0.5 * (uh.x + um.x), 0.5 * (uh.y - um.y));
+                vh = make_double2(0.5 * (vh.x + vm.x), 0.5 * (vh.y - vm.y));
+            }
+            L[(r * NF + k) * LD + pos[i]] = make_double2((uh.x - vh.y) * d.invN2, (uh.y + vh.x) * d.invN2);
+            if (!selfc) L[(rm * NF + k) * LD + pos[N - i]] = make_double2((uh.x + vh.y) * d.invN2, (vh.x - uh.y) * d.invN2);
+        }
+#pragma unroll
+        for (int f = 2; f < 4; ++f) {            // the pairs (q_1 + i q_2) and (p_1 + i p_2)
+            double2 a = f == 2 ? q0 : phk[0], bb = f == 2 ? q1 : phk[1];
+            if (selfc) {
+                const double2 am = f == 2 ? q0m : phm[0], bm = f == 2 ? q1m : phm[1];
+                a = make_double2(0.5 * (a.x + am.x), 0.5 * (a.y - am.y));
+                bb = make_double2(0.5 * (bb.x + bm.x), 0.5 * (bb.y - bm.y));
+            }
+            L[(r * NF + f) * LD + pos[i]] = make_double2((a.x - bb.y) * d.invN2, (a.y + bb.x) * d.invN2);
+            if (!selfc) L[(rm * NF + f) * LD + pos[N - i]] = make_double2((a.x + bb.y) * d.invN2, (bb.x - a.y) * d.invN2);
+        }
+    }
+    __syncthreads();
+    fft_lines_inv_t<NN, NN>(L, nlines, LD, 1, twl);
+#pragma unroll
+    for (int t = threadIdx.x; t < nlines * N; t += NT) {
+        const int e = t % N, line = t / N;
+        const int r = line / NF, f = line - r * NF;
+        const int j = pair_row(p0 + (r >> 1), r & 1, N);
+        dz[((size_t)b * DZF + f) * ZP * N + (size_t)j * ZP + e] = L[line * LD + e];
+    }
+}
+
+template <int NN, int CPBT, int NT>
+__global__ __launch_bounds__(NT) void k_l_cols_diag(SpecDev d, double2 *dz, int ZP) {
+    constexpr int N = NN, LD = N + 1, CPB = CPBT;
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    int *pos = reinterpret_cast<int *>(L + (size_t)DZF * CPB * LD);
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));
+    for (int t = threadIdx.x; t < N; t += NT) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
+    constexpr int groups = N / CPB;
+    const int b = blockIdx.x / groups, c0 = (blockIdx.x - b * groups) * CPB;
+    const size_t fz = (size_t)ZP * N;
+    double2 *g = dz + (size_t)b * DZF * fz;
+    __syncthreads();
+#pragma unroll
+    for (int t = threadIdx.x; t < DZF * CPB * N; t += NT) {
+        const int k = t / (CPB * N), t2 = t - k * CPB * N;
+        const int r = t2 / CPB, c = t2 - r * CPB;
+        L[(k * CPB + c) * LD + pos[r]] = g[(size_t)k * fz + (size_t)r * ZP + c0 + c];
+    }
+    __syncthreads();
+    fft_lines_inv_t<NN, NN>(L, DZF * CPB, LD, 1, twl);
+#pragma unroll
+    for (int t = threadIdx.x; t < CPB * N; t += NT) {
+        const int r = t / CPB, c = t - r * CPB;
+        const double2 uv1 = L[(0 * CPB + c) * LD + r], uv2 = L[(1 * CPB + c) * LD + r];
+        const double2 qq = L[(2 * CPB + c) * LD + r], pp = L[(3 * CPB + c) * LD + r];
+        const double dp = pp.x - pp.y;
+        L[(0 * CPB + c) * LD + r] = make_double2(uv1.x * qq.x, uv1.y * qq.x);
+        L[(1 * CPB + c) * LD + r] = make_double2(uv2.x * qq.y, uv2.y * qq.y);
+        L[(2 * CPB + c) * LD + r] = make_double2(uv1.x * dp, uv1.y * dp);
+        L[(3 * CPB + c) * LD + r] = make_double2(uv2.x * dp, uv2.y * dp);
+    }
+    __syncthreads();
+    fft_lines_fwd_t<NN, NN>(L, DZF * CPB, LD, 1, twl);
+#pragma unroll
+    for (int t = threadIdx.x; t < DZF * CPB * N; t += NT) {
+        const int k = t / (CPB * N), t2 = t - k * CPB * N;
+        const int r = t2 / CPB, c = t2 - r * CPB;
+        g[(size_t)k * fz + (size_t)r * ZP + c0 + c] = L[(k * CPB + c) * LD + pos[r]];
+    }
+}
+
+template <int NN, int PPWT, int NT>
+__global__ __launch_bounds__(NT) void k_l_rows_diag_acc(SpecDev d, DiagConst c, const double2 *dz, const double2 *qh, const double2 *ph,
+                                                        const double2 *Sh, const double2 *dq_p, const double2 *dq_pp, DiagAcc acc, int ZP) {
+    constexpr int NF = DZF, N = NN, NK = N / 2 + 1, LD = N + 1, sz = N * NK, PPW = PPWT, nlines = PPW * 2 * NF;
+    double2 *L = reinterpret_cast<double2 *>(lg_smem);
+    int *pos = reinterpret_cast<int *>(L + (size_t)nlines * LD);
+    double2 *twl = reinterpret_cast<double2 *>(pos + ((N + 3) & ~3));
+    for (int t = threadIdx.x; t < N; t += NT) { pos[t] = d.pos[t]; twl[t] = d.tw[t]; }
+    constexpr int groups = (N / 2) / PPW;
+    const int b = blockIdx.x / groups, p0 = (blockIdx.x - b * groups) * PPW;
+#pragma unroll
+    for (int t = threadIdx.x; t < nlines * N; t += NT) {
+        const int e = t % N, line = t / N;
+        const int r = line / NF, f = line - r * NF;
+        const int j = pair_row(p0 + (r >> 1), r & 1, N);
+        L[line * LD + e] = dz[((size_t)b * DZF + f) * ZP * N + (size_t)j * ZP + e];
+    }
+    __syncthreads();
+    fft_lines_fwd_t<NN, NN>(L, nlines, LD, 1, twl);
+    const double F1 = c.rdm2 * c.del2, F2 = c.rdm2 * c.del1;
+#pragma unroll
+    for (int t = threadIdx.x; t < PPW * 2 * NK; t += NT) {
+        const int i = t % NK, r = t / NK;
+        const int j = pair_row(p0 + (r >> 1), r & 1, N), im = neg_mod_l(i, N);
+        const int rm = (p0 + (r >> 1)) == 0 ? r : (r ^ 1);
+        const int idx = j * NK + i;
+        double2 A[NF], Bv[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const double2 X = L[(r * NF + f) * LD + pos[i]], C = L[(rm * NF + f) * LD + pos[im]];
+            A[f] = make_double2(0.5 * (X.x + C.x), 0.5 * (X.y - C.y));
+            Bv[f] = make_double2(0.5 * (X.y + C.y), -0.5 * (X.x - C.x));
+        }
+        // (ub d, vb d) = del_1 (u_1 d) + del_2 (u_2 d);  (u_1 xi_1) = (u_1 q_1) + F_1 (u_1 d);  (u_2 xi_2) = (u_2 q_2) - F_2 (u_2 d)
+        const double2 A3 = make_double2(c.del1 * A[2].x + c.del2 * A[3].x, c.del1 * A[2].y + c.del2 * A[3].y);
+        const double2 B3 = make_double2(c.del1 * Bv[2].x + c.del2 * Bv[3].x, c.del1 * Bv[2].y + c.del2 * Bv[3].y);
+        const double2 A4 = make_double2(A[0].x + F1 * A[2].x, A[0].y + F1 * A[2].y), B4 = make_double2(Bv[0].x + F1 * Bv[2].x, Bv[0].y + F1 * Bv[2].y);
+        const double2 A5 = make_double2(A[1].x - F2 * A[3].x, A[1].y - F2 * A[3].y), B5 = make_double2(Bv[1].x - F2 * Bv[3].x, Bv[1].y - F2 * Bv[3].y);
+        const size_t o = (size_t)b * 2 * sz + idx, o2 = (size_t)b * sz + idx;
+        const double2 zero = make_double2(0., 0.);
+        diag_accumulate_elem(d, c, acc, idx, i, j, o, o2, sz, qh[o], qh[o + sz], ph[o], ph[o + sz], A3, B3, A4, B4, A5, B5, Sh != nullptr,
+                             Sh ? Sh[o] : zero, Sh ? Sh[o + sz] : zero, A[0], Bv[0], A[1], Bv[1], dq_p[o], dq_p[o + sz], dq_pp[o], dq_pp[o + sz]);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 static int lines_per_block(int N) {
     static const int forced = tune_env("QGX_LARGE_LPB", 0);
@@ -777,6 +945,39 @@ int large_step(qgx_model *m, const StepArgs &a, hipStream_t st) {
     return QGX_OK;
 }
 
+
+// the three launches of one diagnostics increment (kernels above); false: no specialisation for this grid size
+bool large_diag_fused_ok(const qgx_model *m) { return m->opts.large_fused && (m->N == 128 || m->N == 256 || m->N == 512); }
+
+int large_diag_fused(qgx_model *m, const DiagConst &c, const double2 *qh, const double2 *Sh, const double2 *dq_p, const double2 *dq_pp,
+                     const DiagAcc &acc, hipStream_t st) {
+    const SpecDev &d = m->d;
+    const int B = d.B, N = d.N, ZP = N + large_zpad();
+    if (!m->dg_z) {
+        QGX_HIP(hipMalloc((void **)&m->dg_z, (size_t)B * DZF * ZP * N * sizeof(double2)));
+        const int cap = 160 * 1024 - 512;
+#define QGX_DG(NN, P, T1, C, T2)                                                                                               \
+        QGX_HIP(hipFuncSetAttribute((const void *)k_l_rows_diag_inv<NN, P, T1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap)); \
+        QGX_HIP(hipFuncSetAttribute((const void *)k_l_cols_diag<NN, C, T2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));     \
+        QGX_HIP(hipFuncSetAttribute((const void *)k_l_rows_diag_acc<NN, P, T1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+        QGX_DG(128, 4, 512, 8, 1024) QGX_DG(256, 2, 512, 8, 1024) QGX_DG(512, 1, 512, 4, 1024)
+#undef QGX_DG
+    }
+#define QGX_DG(NN, P, T1, C, T2)                                                                                               \
+    {                                                                                                                          \
+        hipLaunchKernelGGL((k_l_rows_diag_inv<NN, P, T1>), dim3(B * (NN / 2 / P)), dim3(T1), lines_lds(NN, 2 * DZF * P), st, d, qh,  \
+                           m->dg_z, m->ph, ZP);                                                                                \
+        hipLaunchKernelGGL((k_l_cols_diag<NN, C, T2>), dim3(B * (NN / C)), dim3(T2), lines_lds(NN, DZF * C), st, d, m->dg_z, ZP); \
+        hipLaunchKernelGGL((k_l_rows_diag_acc<NN, P, T1>), dim3(B * (NN / 2 / P)), dim3(T1), lines_lds(NN, 2 * DZF * P), st, d, c, \
+                           (const double2 *)m->dg_z, qh, (const double2 *)m->ph, Sh, dq_p, dq_pp, acc, ZP);                    \
+    }
+    if (N == 128) QGX_DG(128, 4, 512, 8, 1024)
+    else if (N == 256) QGX_DG(256, 2, 512, 8, 1024)
+    else QGX_DG(512, 1, 512, 4, 1024)
+#undef QGX_DG
+    QGX_HIP(hipGetLastError());
+    return QGX_OK;
+}
 
 // ================================================================================================
 // XCD-resident runs of unparameterized steps (256 x 256).
