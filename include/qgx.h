@@ -249,6 +249,10 @@ int qgx_generator_set_option(qgx_generator *g, const char *name, int value);
  * maxima per layer (10 floats: [0..6] stored activations, [8] layer 1 before its BatchNorm). */
 int qgx_generator_range_read(qgx_generator *g, unsigned *flags, float *input_absmax, void *stream);
 int qgx_generator_info(const qgx_generator *g, int *precision, int *ascale_log2, int *fold, float *layer_absmax);
+/* The 5x5 layer's 1-D Winograd form (conv_wino.hpp; 0.4 x the multiplications of the 25-tap form at 64 x 64): enabled for a
+ * generator only if, at qgx_generator_create, its outputs on calibration inputs stayed within 1e-5 of the exact-f32 kernels'
+ * (relative to the largest output).  -> whether it is in use, what calibration decided, and the error it measured. */
+int qgx_generator_wino_info(const qgx_generator *g, int *enabled, int *chosen_by_calibration, float *calibration_error);
 int qgx_generator_profile(qgx_generator *g, int layer);
 int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches);
 

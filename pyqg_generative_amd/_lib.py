@@ -86,6 +86,7 @@ SYMBOLS = [
     ('qgx_generator_range_read', C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.c_void_p]),
     ('qgx_generator_info', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_float)]),
+    ('qgx_generator_wino_info', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ('qgx_generator_profile', C.c_int, [C.c_void_p, C.c_int]),
     ('qgx_generator_profile_read', C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ('qgx_noise_normal', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,

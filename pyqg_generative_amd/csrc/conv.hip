@@ -45,6 +45,7 @@ extern __shared__ __attribute__((aligned(16))) char conv_smem[];
 
 #include "conv_half.hpp"
 #include "conv_pair.hpp"
+#include "conv_wino.hpp"
 // Kernel variants that were measured slower than the ones above (k_convh generic / plain f16, k_convh_res,
 // k_convh3 on 16x16x32 MFMAs, k_convh4 with full-line chunks) are compiled only into the A/B library
 // (`make ab` -> libqgx_ab.so, bench_tools/ab_conv.py): the product library carries one path per layer and size.
@@ -657,6 +658,17 @@ __global__ void k_absmax(const float *x, size_t n, unsigned *range) {
     input_absmax(m, range);
 }
 
+// out[0] = max |a - b|, out[1] = max |b| (float bits; calibration of the Winograd layer against the exact-f32 path)
+__global__ void k_absdiff_max(const float *a, const float *b, size_t n, unsigned *out) {
+    float d = 0.f, m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        d = fmaxf(d, abs_or_inf(a[i] - b[i]));
+        m = fmaxf(m, abs_or_inf(b[i]));
+    }
+    for (int o = 32; o > 0; o >>= 1) { d = fmaxf(d, __shfl_down(d, o)); m = fmaxf(m, __shfl_down(m, o)); }
+    if ((threadIdx.x & 63) == 0) { atomicMax(out, __float_as_uint(d)); atomicMax(out + 1, __float_as_uint(m)); }
+}
+
 // Fused sampler update + input assembly of one online step (GAN / VAE):
 //   z <- a z + b xi  (float; xi from Philox or the external draw), X = [float(q)/x_std, z]
 // One thread per quad of 4 consecutive elements of the (2,N,N) member field.
@@ -781,6 +793,10 @@ struct LayerHost {
     // layer 2 with layer 1's BatchNorm folded in (W' = W alpha[c_in], b' = b + sum W beta'[c_in]; exact under circular
     // padding): layer 1 then stores ReLU output, half of which is exactly zero -> a sparser MFMA operand
     void *whF = nullptr, *wh16F = nullptr; float whF_unscale = 1.f; float *biasF = nullptr;
+    // layer 2 as a 1-D Winograd convolution F(4, 5) along x (conv_wino.hpp): transformed weights, [0] plain, [1] with layer
+    // 1's BatchNorm folded in; per-position 2^-s of the power-of-two pre-scale
+    void *ww[2] = {nullptr, nullptr};
+    float ww_unscale[2][8] = {{1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1}};
     float *ones = nullptr, *zeros = nullptr; // layer 1: identity BatchNorm for the folded variant
     void *wh16 = nullptr;                    // k_convh3 (16x16x32 MFMA): [chunk32][tap][part][octet][cout][8] f16
     void *whf = nullptr;                     // first layer, f16x3: [step][part][h][128][8] f16
@@ -814,6 +830,11 @@ struct qgx_generator {
     int opt_prio_alt = 1;          // k_convh2 with two workgroups per CU: alternate their wave priority per tile
     int opt_h4 = 0;                // 5x5 layer: k_convh4 (full-line patch chunks, 8 waves, R = 8)
     int opt_h2_grid = 0;           // k_convh2: persistent workgroups per launch (0 = one or two per CU by LDS size)
+    int opt_wino = 1;              // f16x3, 64 x 64: the 5x5 layer as a 1-D Winograd convolution F(4, 5) along x (k_convw)
+    int auto_wino = 0;             //   ... what calibrate_wino() decided, and the error it measured for it
+    float wino_err = 0.f;
+    int opt_wino_exp = 0;          //   A/B library: timing experiments (conv_wino.hpp EXP)
+    int opt_wino_min_tiles = 128;  //   ... from this many 8-row tiles on (below it the persistent workgroups do not fill the CUs)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
     int opt_part_max_tiles = 112;  // f16x3: split K on the wide layers below this many tiles (crossover: 7 members at 64x64)
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
@@ -929,6 +950,65 @@ static int pack_half(LayerHost &L, int li, const qgx_cnn_weights *w, int NS, con
     return QGX_OK;
 }
 
+// conv_wino.hpp weight layout [chunk][ky][p][part][h][cout][8] f16: U_p,ky(o, c) = sum_kx G[p][kx] w(o, c, ky, kx) of the
+// Toom-Cook algorithm F(4, 5) with the points 0, +-1, +-2, +-1/2, infinity, evaluated in float64, pre-scaled per position by
+// 2^s_p with max|U_p| 2^s_p in [2^13, 2^14), split into f16 hi / lo
+static const double WINO_G[8][5] = {{-1, 0, 0, 0, 0},
+                                    {-2. / 9, -2. / 9, -2. / 9, -2. / 9, -2. / 9},
+                                    {-2. / 9, 2. / 9, -2. / 9, 2. / 9, -2. / 9},
+                                    {1. / 90, 2. / 90, 4. / 90, 8. / 90, 16. / 90},
+                                    {1. / 90, -2. / 90, 4. / 90, -8. / 90, 16. / 90},
+                                    {32. / 45, 16. / 45, 8. / 45, 4. / 45, 2. / 45},
+                                    {32. / 45, -16. / 45, 8. / 45, -4. / 45, 2. / 45},
+                                    {0, 0, 0, 0, 1}};
+static const float WINO_AT[4][8] = {{1, 1, 1, 1, 1, 1, 1, 0},
+                                    {0, 1, -1, 2, -2, .5f, -.5f, 0},
+                                    {0, 1, 1, 4, 4, .25f, .25f, 0},
+                                    {0, 1, -1, 8, -8, .125f, -.125f, 1}};
+static int pack_wino(LayerHost &L, int li, const qgx_cnn_weights *w, const float *cin_scale, int which) {
+    const int cin = L.cin, cout = L.cout;
+    if (cin != 128 || cout != 64 || L.ks != 5) return QGX_OK;
+    const int nch = cin / 16;
+    const float *W = w->conv_w[li];
+    std::vector<double> U((size_t)8 * 5 * cout * cin);
+    double mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < 8; ++p)
+        for (int ky = 0; ky < 5; ++ky)
+            for (int co = 0; co < cout; ++co)
+                for (int c = 0; c < cin; ++c) {
+                    double u = 0.0;
+                    for (int kx = 0; kx < 5; ++kx)
+                        u += WINO_G[p][kx] * (double)W[((size_t)co * cin + c) * 25 + ky * 5 + kx];
+                    u *= cin_scale ? (double)cin_scale[c] : 1.0;
+                    U[(((size_t)p * 5 + ky) * cout + co) * cin + c] = u;
+                    mx[p] = fmax(mx[p], fabs(u));
+                }
+    std::vector<_Float16> pw((size_t)nch * 5 * 8 * 4 * cout * 8, (_Float16)0.f);
+    for (int p = 0; p < 8; ++p) {
+        int e = 0;
+        if (mx[p] > 0.) (void)frexp(mx[p], &e);
+        int sexp = 14 - e;
+        sexp = sexp < -20 ? -20 : (sexp > 40 ? 40 : sexp);
+        const double sc = ldexp(1.0, sexp);
+        L.ww_unscale[which][p] = ldexpf(1.f, -sexp);
+        for (int ch = 0; ch < nch; ++ch)
+            for (int ky = 0; ky < 5; ++ky)
+                for (int j = 0; j < 2; ++j)
+                    for (int hh = 0; hh < 2; ++hh)
+                        for (int co = 0; co < cout; ++co)
+                            for (int e8 = 0; e8 < 8; ++e8) {
+                                const int c = ch * 16 + hh * 8 + e8;
+                                const float x = (float)(U[(((size_t)p * 5 + ky) * cout + co) * cin + c] * sc);
+                                const _Float16 xh = (_Float16)x;
+                                pw[((((((size_t)ch * 5 + ky) * 8 + p) * 2 + j) * 2 + hh) * cout + co) * 8 + e8] =
+                                    j == 0 ? xh : (_Float16)(x - (float)xh);
+                            }
+    }
+    QGX_HIP(hipMalloc(&L.ww[which], pw.size() * sizeof(_Float16)));
+    QGX_HIP(hipMemcpy(L.ww[which], pw.data(), pw.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    return QGX_OK;
+}
+
 // k_convh3 layout: 32-channel chunks, [chunk][tap][part][octet][cout][8]; same power-of-two pre-scale as wh[1]
 static int pack_half16(LayerHost &L, int li, const qgx_cnn_weights *w, const float *cin_scale = nullptr) {
     const int cin = L.cin, cout = L.cout, T = L.ks * L.ks, nch = cin / 32;
@@ -1035,6 +1115,7 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
                     bf[co] = (float)acc;
                 }
                 if ((rc = pack_half(L, li, w, 2, al.data())) || (rc = upf(L.biasF, bf))) return rc;
+                if ((rc = pack_wino(L, li, w, nullptr, 0)) || (rc = pack_wino(L, li, w, al.data(), 1))) return rc;
 #ifdef QGX_AB
                 if ((rc = pack_half16(L, li, w, al.data()))) return rc;
 #endif
@@ -1733,6 +1814,37 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
     return QGX_OK;
 }
 
+// layer 2 as a 1-D Winograd convolution (conv_wino.hpp); done = false: no specialisation for this grid / ensemble size
+static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int which, const void *in, void *out, int B, int N,
+                        hipStream_t st, bool &done) {
+    done = false;
+    if (!g->opt_wino || N != 64 || !L.ww[which] || B * (N / 8) < g->opt_wino_min_tiles) return QGX_OK;
+    hipEvent_t prof_stop;
+    { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
+    ConvWArgs a = {};
+    a.in = in; a.out = out; a.w = L.ww[which]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+    for (int j = 0; j < 4; ++j)
+        for (int p = 0; p < 8; ++p) a.atp[j][p] = WINO_AT[j][p] * L.ww_unscale[which][p] / g->opt_ascale;
+    a.ascale = g->opt_ascale;
+    a.range = g->range_dev; a.range_bit = 1u << layer;
+    const int total_tiles = B * (N / 8);
+    const size_t lds = (size_t)8 * 12 * (N / 4) * 64 + (size_t)12 * 4 * N * 16 + (3 * 64 + 32) * sizeof(float);   // transformed + raw patch
+    const int grid = total_tiles < 256 ? total_tiles : 256;
+    void (*kern)(ConvWArgs, int) = k_convw<64>;
+#ifdef QGX_AB       // timing experiments: parts of the kernel switched off (wrong results)
+    if (g->opt_wino_exp == 1) kern = k_convw<64, 1>;
+    else if (g->opt_wino_exp == 2) kern = k_convw<64, 2>;
+    else if (g->opt_wino_exp == 4) kern = k_convw<64, 4>;
+    else if (g->opt_wino_exp == 5) kern = k_convw<64, 5>;
+#endif
+    { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
+    QGX_HIP(hipGetLastError());
+    if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+    done = true;
+    return QGX_OK;
+}
+
 template <int NS>
 static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x, float *y, int B, int N,
                             hipStream_t st) {
@@ -1764,6 +1876,7 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         const bool tiny = NS == 2 && g->opt_h2 == 3 && r2 > 0 && Bc * (N / r2) < g->opt_part_max_tiles;
         bool done1 = false;
         if (tiny && (rc = launch_convh2_part<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && NS == 2 && (rc = launch_convw(g, 1, L1, fold ? 1 : 0, A, Bb, Bc, N, st, done1))) return rc;
 #ifdef QGX_AB
         if (!done1 && NS == 2 && g->opt_h4 && (rc = launch_convh4(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
@@ -1894,6 +2007,68 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
 //   * "fold" (layer 1 stores its pre-BatchNorm ReLU output) only if that tensor fits the same window;
 //   * if the layer maxima span more than the window (2^12), f16x3 cannot be float32-class for this net:
 //     precision 0 (the exact-f32 MFMA kernels) becomes the default.
+// The 1-D Winograd form of the 5x5 layer (conv_wino.hpp) multiplies 0.4 x as much, but its float32 transforms and
+// accumulators carry the condition of the Toom-Cook matrices: for the layer, 3-4 x the rounding error of the 25-tap form
+// (float32 evaluation of both: tests/test_conv_transform_numerics_cpu.py), and how much of that reaches the net's output
+// depends on the weights behind it (shipped nets: 3e-6 ... 9e-6 of max|y|; random-weight nets up to 5e-5).  So it is
+// MEASURED per generator: every net is evaluated at 64 x 64 on calibration inputs (white noise, one member hotter; smooth
+// fields; constants) with the Winograd layer and with the exact-f32 kernels, and the Winograd form becomes the default only
+// if the largest difference stays below WINO_MAX_ERR of the largest output — half of the tolerance the golden vectors are
+// held to.  (qgx_generator_wino_info reports the decision; option "wino" overrides it.)
+static constexpr float WINO_MAX_ERR = 1e-5f;
+static int calibrate_wino(qgx_generator *g) {
+    g->auto_wino = 0; g->wino_err = 0.f; g->opt_wino = 0;
+    if (g->opt_precision != 3) return QGX_OK;
+    const int N = 64, B = 8, npix = N * N;
+    int rc = reserve(g, B, N);
+    if (rc) return rc;
+    unsigned *cd = nullptr;
+    QGX_HIP(hipMalloc((void **)&cd, 2 * sizeof(unsigned)));
+    QGX_HIP(hipMemset(cd, 0, 2 * sizeof(unsigned)));
+    const int saved_part = g->opt_part_max_tiles, saved_min = g->opt_wino_min_tiles;
+    float worst = 0.f;
+    for (int n = 0; n < g->n_nets && !rc; ++n) {
+        const NetHost &net = g->nets[n];
+        if (!net.L[1].ww[0]) { worst = INFINITY; break; }
+        std::vector<float> x((size_t)B * net.n_in * npix);
+        uint32_t lcg = 54321u + 977u * n;
+        auto uni = [&]() { lcg = lcg * 1664525u + 1013904223u; return ((lcg >> 8) + 0.5f) * (1.0f / 16777216.0f); };
+        for (int b = 0; b < B; ++b)
+            for (int c = 0; c < net.n_in; ++c)
+                for (int y = 0; y < N; ++y)
+                    for (int xx = 0; xx < N; ++xx) {
+                        float v;
+                        const float white = sqrtf(-2.f * logf(uni())) * cosf(6.2831853f * uni());
+                        if (b < 5) v = white * (b == 3 ? 2.f : (b == 4 ? 1.5f : 1.f));
+                        else if (b < 7) v = 2.f * sinf(6.2831853f * (y * (c + 1) + xx * (b - 4)) / N)
+                                            + cosf(6.2831853f * 2 * xx / N) + 0.3f * white;
+                        else v = 3.f * ((c & 1) ? -1.f : 1.f);
+                        x[(((size_t)b * net.n_in + c) * N + y) * N + xx] = v;
+                    }
+        QGX_HIP(hipMemcpy(g->X, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice));
+        g->opt_precision = 0;
+        rc = cnn_forward(g, net, g->X, g->Y0, B, N, nullptr);
+        g->opt_precision = 3; g->opt_wino = 1; g->opt_wino_min_tiles = 1; g->opt_part_max_tiles = 0;
+        if (!rc) rc = cnn_forward(g, net, g->X, g->Y1, B, N, nullptr);
+        g->opt_wino = 0; g->opt_wino_min_tiles = saved_min; g->opt_part_max_tiles = saved_part;
+        if (rc) break;
+        QGX_HIP(hipMemset(cd, 0, 2 * sizeof(unsigned)));
+        hipLaunchKernelGGL(k_absdiff_max, dim3(64), dim3(256), 0, nullptr, (const float *)g->Y1, (const float *)g->Y0,
+                           (size_t)B * net.n_out * npix, cd);
+        float h[2];
+        QGX_HIP(hipMemcpy(h, cd, sizeof(h), hipMemcpyDeviceToHost));
+        const float err = h[1] > 0.f ? h[0] / h[1] : INFINITY;
+        worst = fmaxf(worst, std::isfinite(err) ? err : INFINITY);
+    }
+    (void)hipFree(cd);
+    QGX_HIP(hipMemset(g->range_dev, 0, 2 * sizeof(unsigned)));     // the calibration runs are not the caller's
+    if (rc) return rc;
+    g->wino_err = worst;
+    g->auto_wino = worst <= WINO_MAX_ERR ? 1 : 0;
+    g->opt_wino = g->auto_wino;
+    return QGX_OK;
+}
+
 static int calibrate(qgx_generator *g) {
     QGX_HIP(hipMalloc((void **)&g->range_dev, 2 * sizeof(unsigned)));
     QGX_HIP(hipMemset(g->range_dev, 0, 2 * sizeof(unsigned)));
@@ -2051,6 +2226,7 @@ extern "C" int qgx_generator_create(int kind, const qgx_cnn_weights *nets, int n
     }
     {
         int rc = calibrate(g);
+        if (!rc) rc = calibrate_wino(g);
         if (rc) { qgx_generator_destroy(g); return rc; }
     }
     *out = g;
@@ -2065,6 +2241,14 @@ extern "C" int qgx_generator_range_read(qgx_generator *g, unsigned *flags, float
     QGX_HIP(hipStreamSynchronize((hipStream_t)stream));
     *flags = h[0];
     memcpy(input_absmax, &h[1], sizeof(float));
+    return QGX_OK;
+}
+
+extern "C" int qgx_generator_wino_info(const qgx_generator *g, int *enabled, int *chosen_by_calibration, float *calibration_error) {
+    QGX_REQUIRE(g, "qgx_generator_wino_info: null generator");
+    if (enabled) *enabled = g->opt_wino;
+    if (chosen_by_calibration) *chosen_by_calibration = g->auto_wino;
+    if (calibration_error) *calibration_error = g->wino_err;
     return QGX_OK;
 }
 
@@ -2089,6 +2273,7 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             if (L.whf) (void)hipFree(L.whf);
             if (L.wh16) (void)hipFree(L.wh16);
             if (L.whF) (void)hipFree(L.whF);
+            for (void *pw_ : L.ww) if (pw_) (void)hipFree(pw_);
             if (L.wh16F) (void)hipFree(L.wh16F);
             for (float *p : {L.biasF, L.ones, L.zeros}) if (p) (void)hipFree(p);
         }
@@ -2159,6 +2344,11 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "last_rows")) g->opt_last_rows = value;
     else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;
     else if (!strcmp(name, "fold")) g->opt_fold = value ? 1 : 0;
+    else if (!strcmp(name, "wino")) g->opt_wino = value ? 1 : 0;
+#ifdef QGX_AB
+    else if (!strcmp(name, "wino_exp")) g->opt_wino_exp = value;
+#endif
+    else if (!strcmp(name, "wino_min_tiles")) { QGX_REQUIRE(value >= 1, "wino_min_tiles must be >= 1"); g->opt_wino_min_tiles = value; }
     else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
     else if (!strcmp(name, "h4")) g->opt_h4 = value;
     else if (!strcmp(name, "prio_alt")) g->opt_prio_alt = value;
@@ -2171,7 +2361,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
     else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= -24 && value <= 24, "ascale_log2 must be in -24..24"); g->opt_ascale = ldexpf(1.f, value); }
     else if (!strcmp(name, "prof_every")) { QGX_REQUIRE(value >= 1, "prof_every must be >= 1"); g->prof_every = value; }
-    else if (!strcmp(name, "auto")) { g->opt_precision = g->auto_precision; g->opt_fold = g->auto_fold; g->opt_ascale = ldexpf(1.f, g->auto_ascale_log2); }
+    else if (!strcmp(name, "auto")) { g->opt_precision = g->auto_precision; g->opt_fold = g->auto_fold; g->opt_ascale = ldexpf(1.f, g->auto_ascale_log2); g->opt_wino = g->auto_wino; }
     else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;

