@@ -1815,10 +1815,9 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
 }
 
 // layer 2 as a 1-D Winograd convolution (conv_wino.hpp); done = false: no specialisation for this grid / ensemble size
-static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int which, const void *in, void *out, int B, int N,
-                        hipStream_t st, bool &done) {
-    done = false;
-    if (!g->opt_wino || N != 64 || !L.ww[which] || B * (N / 8) < g->opt_wino_min_tiles) return QGX_OK;
+template <int NN, int TW, int R>
+static int launch_convw_n(qgx_generator *g, int layer, const LayerHost &L, int which, const void *in, void *out, int B,
+                          hipStream_t st) {
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
     ConvWArgs a = {};
@@ -1827,22 +1826,49 @@ static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int whi
         for (int p = 0; p < 8; ++p) a.atp[j][p] = WINO_AT[j][p] * L.ww_unscale[which][p] / g->opt_ascale;
     a.ascale = g->opt_ascale;
     a.range = g->range_dev; a.range_bit = 1u << layer;
-    const int total_tiles = B * (N / 8);
-    const size_t lds = (size_t)8 * 12 * (N / 4) * 64 + (size_t)12 * 4 * N * 16 + (3 * 64 + 32) * sizeof(float);   // transformed + raw patch
+    const int total_tiles = B * (NN / R) * (NN / TW);
+    constexpr size_t lds = convw_lds_bytes(NN, TW, R);
+    static_assert(lds <= 160 * 1024 - 256, "k_convw: LDS");
     const int grid = total_tiles < 256 ? total_tiles : 256;
-    void (*kern)(ConvWArgs, int) = k_convw<64>;
+    void (*kern)(ConvWArgs, int) = k_convw<NN, TW, R>;
 #ifdef QGX_AB       // timing experiments: parts of the kernel switched off (wrong results)
-    if (g->opt_wino_exp == 1) kern = k_convw<64, 1>;
-    else if (g->opt_wino_exp == 2) kern = k_convw<64, 2>;
-    else if (g->opt_wino_exp == 4) kern = k_convw<64, 4>;
-    else if (g->opt_wino_exp == 5) kern = k_convw<64, 5>;
+    if (g->opt_wino_exp == 1) kern = k_convw<NN, TW, R, 1>;
+    else if (g->opt_wino_exp == 2) kern = k_convw<NN, TW, R, 2>;
+    else if (g->opt_wino_exp == 4) kern = k_convw<NN, TW, R, 4>;
+    else if (g->opt_wino_exp == 5) kern = k_convw<NN, TW, R, 5>;
 #endif
     { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
-    done = true;
     return QGX_OK;
+}
+// tiles of 512 pixels: 8 x 64 (64 x 64, 128 x 128), 16 x 32 (96 x 96, 32 x 32); 16 x 16 at 48 x 48
+static int wino_tiles(int B, int N) {
+    switch (N) {
+        case 32: return B * 2;
+        case 48: return B * 9;
+        case 64: return B * 8;
+        case 96: return B * 18;
+        case 128: return B * 32;
+        default: return 0;
+    }
+}
+static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int which, const void *in, void *out, int B, int N,
+                        hipStream_t st, bool &done) {
+    done = false;
+    const int tiles = wino_tiles(B, N);
+    if (!g->opt_wino || !L.ww[which] || tiles == 0 || tiles < g->opt_wino_min_tiles) return QGX_OK;
+    int rc;
+    switch (N) {
+        case 32: rc = launch_convw_n<32, 32, 16>(g, layer, L, which, in, out, B, st); break;
+        case 48: rc = launch_convw_n<48, 16, 16>(g, layer, L, which, in, out, B, st); break;
+        case 64: rc = launch_convw_n<64, 64, 8>(g, layer, L, which, in, out, B, st); break;
+        case 96: rc = launch_convw_n<96, 32, 16>(g, layer, L, which, in, out, B, st); break;
+        default: rc = launch_convw_n<128, 64, 8>(g, layer, L, which, in, out, B, st); break;
+    }
+    if (!rc) done = true;
+    return rc;
 }
 
 template <int NS>

@@ -17,7 +17,8 @@
 // max|y| for this layer with the f16x3 split applied AFTER the input transform — the float32 error class (direct float32:
 // 2.2e-7; the 25-tap f16x3 kernel: same class).
 //
-// One workgroup = 8 waves owns R = 8 full-width output rows; wave p owns POSITION p: its A operand U_p,ky comes straight
+// One workgroup = 8 waves owns a tile of R rows x TW columns (512 pixels: 8 x 64 at 64 x 64, 16 x 32 at 96 x 96 and
+// 32 x 32, 8 x 64 at 128 x 128; 16 x 16 at 48 x 48); wave p owns POSITION p: its A operand U_p,ky comes straight
 // from global memory / L2 in fragment layout (no other wave uses it, so staging it through LDS would only add barriers),
 // its B operand V_p from the transformed patch in LDS ([p][row][quad] records of 64 payload + 16 pad bytes), its
 // accumulators are M_p of the whole tile (4 M-tiles of 32 (row, quad) pairs x 64 output channels = 128 registers).
@@ -73,68 +74,85 @@ __device__ __forceinline__ void wino_bt8(const float (&x)[8][4], int e, float (&
 
 // EXP (A/B library, timing experiments only — the results are wrong): 1 no input transform, 2 no MFMAs, 4 weights loaded
 // once, 5 no raw-patch copy
-template <int NN, int EXP = 0>
+template <int NN, int TW, int R, int EXP = 0>
 __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
     constexpr int N = NN, CIN = 128, COUT = 64, NCH = CIN / 16, KY = 5;
-    constexpr int NQ = N / 4;                       // quads per row
-    constexpr int RM = 32 / NQ;                     // rows per M-tile of 32 (row, quad) pairs
-    constexpr int R = 8, MT = R / RM, PR = R + 4;   // output rows, M-tiles, patch rows of a tile
+    constexpr int NQT = TW / 4;                     // quads per tile row
+    constexpr int RM = 32 / NQT;                    // rows per M-tile of 32 (row, quad) pairs
+    constexpr int MT = R / RM, PR = R + 4;          // M-tiles, patch rows of a tile
+    constexpr int XT = N / TW;
+    constexpr bool FULLW = TW == N;                 // full-width tiles: the x halo is the row itself, wrapped
+    constexpr int PW = FULLW ? N : TW + 4;          // patch columns held in LDS: x0 - 2 ... x0 + TW + 1 (wrapped)
+    constexpr int SQ = PW / 4;                      // quads of the raw patch: column slot = SQ (xl & 3) + (xl >> 2)
     constexpr int PIXB = CIN * 4, OPIXB = COUT * 4;
     // LDS: the transformed patch VT[p][row][quad] in 64-byte records whose four 16-byte units (octet 0 hi | lo, octet 1
-    // hi | lo) are XOR-swizzled by bits 2..3 of the quad (conflict-free ds_read_b128 of 16 consecutive quads without
-    // padding); the RAW patch of the NEXT chunk, transposed to [row][unit][column slot] with slot = 16 (x & 3) + (x >> 2),
-    // so that the transform's reads of 16 consecutive quads are 16 consecutive 16-byte slots
+    // hi | lo) are XOR-swizzled by bits 2..3 of the record's pair index row * NQT + quad (conflict-free ds_read_b128 of 16
+    // consecutive pairs without padding); the RAW patch of the NEXT chunk, transposed to [row][unit][column slot] with
+    // slot = SQ (xl & 3) + (xl >> 2) for the local column xl = x - (x0 - 2) (full-width tiles: xl = x), so that the
+    // transform's reads of consecutive quads are consecutive 16-byte slots
     constexpr int REC = 64;
-    constexpr int VT_BYTES = 8 * PR * NQ * REC;
-    constexpr int RAW_BYTES = PR * 4 * N * 16;
+    constexpr int VT_BYTES = 8 * PR * NQT * REC;
     constexpr int MREC = COUT * 4 + 16;             // output staging: bytes per (p, pair) record
-    constexpr int NITEM = PR * NQ * 2;              // transform items (row, quad, octet) per chunk
-    constexpr int NUNIT = PR * N * 4;               // 16-byte units of a chunk's raw patch
-    constexpr int UPT = NUNIT / 512;                // ... per thread
-    static_assert(N == 64 && 32 % NQ == 0 && R % RM == 0 && NITEM <= 512 && NUNIT % 512 == 0 && UPT == 6, "tile shape");
-    static_assert(8 * 32 * MREC <= VT_BYTES, "output staging fits the patch region");
+    constexpr int A_BYTES = VT_BYTES > 8 * 32 * MREC ? VT_BYTES : 8 * 32 * MREC;
+    constexpr int RAW_BYTES = PR * 4 * PW * 16;
+    constexpr int NITEM = PR * NQT * 2;             // transform items (row, quad, octet) per chunk
+    constexpr int NUNIT = PR * PW * 4;              // 16-byte units of a chunk's raw patch
+    constexpr int UPT = (NUNIT + 511) / 512;        // ... per thread
+    static_assert(32 % NQT == 0 && R % RM == 0 && N % TW == 0 && N % R == 0 && NITEM <= 512 && UPT <= 7, "tile shape");
     char *const vt = conv_smem;
-    char *const rawb = conv_smem + VT_BYTES;
-    float *const ep = reinterpret_cast<float *>(conv_smem + VT_BYTES + RAW_BYTES);       // bias | scale | shift | AT'[4][8]
+    char *const rawb = conv_smem + A_BYTES;
+    float *const ep = reinterpret_cast<float *>(conv_smem + A_BYTES + RAW_BYTES);         // bias | scale | shift | AT'[4][8]
     const char *const inb = reinterpret_cast<const char *>(a.in);
     const char *const wb = reinterpret_cast<const char *>(a.w);
     const int lane = threadIdx.x & 63, p = threadIdx.x >> 6;                 // wave p owns position p
     const int li = lane & 31, h = lane >> 5;
-    constexpr int tiles_per_img = N / R;
+    constexpr int tiles_per_img = (N / R) * XT;
     const int n_my = blockIdx.x < (unsigned)total_tiles ? (total_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     if (n_my == 0) return;
     for (int i = threadIdx.x; i < 3 * COUT + 32; i += 512)
         ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : (i < 3 * COUT ? a.shift[i - 2 * COUT] : a.atp[(i - 3 * COUT) >> 3][(i - 3 * COUT) & 7]));
 
-    // transform item of this thread: lanes run over the quads first (16 consecutive slots of the raw patch)
-    const int it_t = threadIdx.x % NQ, it_o = (threadIdx.x / NQ) & 1, it_r = threadIdx.x / (2 * NQ);
+    // transform item of this thread: lanes run over the quads first (consecutive slots of the raw patch)
+    const int it_t = threadIdx.x % NQT, it_o = (threadIdx.x / NQT) & 1, it_r = threadIdx.x / (2 * NQT);
     const bool has_item = threadIdx.x < NITEM;
-    const int it_sw = (it_t >> 2) & 3;
-    // B-fragment base of this lane: pair li = (row li / NQ, quad li % NQ) of an M-tile, octet h (units 2h, 2h + 1, swizzled)
-    const int fq = li % NQ;
-    const int fbase = ((p * PR + li / NQ) * NQ + fq) * REC + (((2 * h) ^ ((fq >> 2) & 3)) * 16);
+    const int it_sw = ((it_r * NQT + it_t) >> 2) & 3;
+    // B fragment of this lane: pair li = (row li / NQT, quad li % NQT) of an M-tile, octet h (units 2h | 2h + 1, swizzled)
+    const int fq = li % NQT, fr = li / NQT;
+    const int fbase = ((p * PR + fr) * NQT + fq) * REC + (((2 * h) ^ (((fr * NQT + fq) >> 2) & 3)) * 16);
+    auto frag = [&](int row_off) -> int {        // byte offset of the hi unit of patch row fr + row_off; the lo unit is ^ 16
+        if constexpr (NQT == 16) return fbase + row_off * NQT * REC;                         // swizzle: the quad alone
+        else if constexpr (NQT == 8) return (fbase + row_off * NQT * REC) ^ ((row_off & 1) * 32);   // ... and the row's parity
+        else {
+            const int prow = fr + row_off;
+            return ((p * PR + prow) * NQT + fq) * REC + (((2 * h) ^ (((prow * NQT + fq) >> 2) & 3)) * 16);
+        }
+    };
     // A-fragment base: [p][part][h][cout][8] within a (chunk, ky) slice of 8 * 4 * 64 * 16 bytes
     const int wofs = (p * 4 + h) * COUT * 16 + li * 16;
     constexpr int WSLICE = 8 * 4 * COUT * 16;
 
     // ---- raw patch of (tile, chunk): unit j of this thread, global -> register -> LDS ----
-    // unit u = j * 512 + tid = ((row * N + x) * 4 + unit-in-pixel): consecutive lanes read the 64 contiguous bytes of a
+    // unit u = j * 512 + tid = ((row * PW + xl) * 4 + unit-in-pixel): consecutive lanes read the 64 contiguous bytes of a
     // pixel's chunk and consecutive pixels.  (LDS-DMA would need no registers, but while one is in flight hipcc drains
     // vmcnt(0) at every use of an ordinary load — here the weight fragments of every block.)
 #define QGX_RAW_LOAD(J, TILE, CH, DST)                                                                          \
     {                                                                                                           \
-        const int u_ = (J) * 512 + (int)threadIdx.x;                                                            \
-        const int un_ = u_ & 3, x_ = (u_ >> 2) & (N - 1), r_ = u_ / (4 * N);                                    \
-        const int b_ = (TILE) / tiles_per_img;                                                                  \
-        int gy_ = ((TILE) - b_ * tiles_per_img) * R - 2 + r_;                                                   \
+        int u_ = (J) * 512 + (int)threadIdx.x;                                                                  \
+        u_ = u_ < NUNIT ? u_ : NUNIT - 1;                                                                       \
+        const int un_ = u_ & 3, xl_ = (u_ >> 2) % PW, r_ = u_ / (4 * PW);                                       \
+        const int b_ = (TILE) / tiles_per_img, tr_ = (TILE) - b_ * tiles_per_img;                               \
+        int gy_ = (tr_ / XT) * R - 2 + r_, gx_ = FULLW ? xl_ : (tr_ % XT) * TW - 2 + xl_;                       \
         gy_ = gy_ < 0 ? gy_ + N : (gy_ >= N ? gy_ - N : gy_);                                                   \
-        DST = *reinterpret_cast<const f32x4 *>(inb + (((size_t)b_ * N + gy_) * N + x_) * PIXB + (CH) * 64 + un_ * 16); \
+        gx_ = gx_ < 0 ? gx_ + N : (gx_ >= N ? gx_ - N : gx_);                                                   \
+        DST = *reinterpret_cast<const f32x4 *>(inb + (((size_t)b_ * N + gy_) * N + gx_) * PIXB + (CH) * 64 + un_ * 16); \
     }
 #define QGX_RAW_STORE(J, SRC)                                                                                   \
     {                                                                                                           \
         const int u_ = (J) * 512 + (int)threadIdx.x;                                                            \
-        const int un_ = u_ & 3, x_ = (u_ >> 2) & (N - 1), r_ = u_ / (4 * N);                                    \
-        *reinterpret_cast<f32x4 *>(rawb + (((r_ * 4 + un_) * N) + (x_ & 3) * NQ + (x_ >> 2)) * 16) = SRC;       \
+        if (u_ < NUNIT) {                                                                                       \
+            const int un_ = u_ & 3, xl_ = (u_ >> 2) % PW, r_ = u_ / (4 * PW);                                   \
+            *reinterpret_cast<f32x4 *>(rawb + (((r_ * 4 + un_) * PW) + (xl_ & 3) * SQ + (xl_ >> 2)) * 16) = SRC;       \
+        }                                                                                                       \
     }
 
     f32x16 acc[MT][2];
@@ -154,14 +172,14 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
 
     for (int ti = 0; ti < n_my; ++ti) {
         const int tile_g = blockIdx.x + ti * gridDim.x;
-        const int b = tile_g / tiles_per_img;
-        const int y0 = (tile_g - b * tiles_per_img) * R;
+        const int b = tile_g / tiles_per_img, tr = tile_g - b * tiles_per_img;
+        const int y0 = (tr / XT) * R, x0 = (tr % XT) * TW;
         for (int ch = 0; ch < NCH; ++ch) {
             // ---- input transform of this chunk: raw patch (LDS) -> float32 BT -> hi / lo -> transformed patch (LDS) ----
             __syncthreads();        // the raw patch has landed; every wave is done reading the previous transformed patch
             if (has_item && EXP != 1) {
-                const char *src = rawb + (size_t)(it_r * 4 + it_o * 2) * N * 16;
-                char *dst = vt + ((size_t)it_r * NQ + it_t) * REC;
+                const char *src = rawb + (size_t)(it_r * 4 + it_o * 2) * PW * 16;
+                char *dst = vt + ((size_t)it_r * NQT + it_t) * REC;
                 const int uh = ((2 * it_o) ^ it_sw) * 16, ul = uh ^ 16;
                 // two halves of 4 channels: the tile's 128 accumulators stay live, which leaves ~100 registers here
 #pragma nounroll
@@ -169,10 +187,12 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                     u32x2 raw[8][2];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        // x = 4 t - 2 + k: column slot 16 (x & 3) + (x >> 2), x >> 2 = t - 1, t, t + 1 (mod NQ)
-                        const int c = (k + 2) & 3, tq = (it_t + (k < 2 ? NQ - 1 : (k < 6 ? 0 : 1))) & (NQ - 1);
-                        raw[k][0] = *reinterpret_cast<const u32x2 *>(src + (c * NQ + tq) * 16 + hf * 8);
-                        raw[k][1] = *reinterpret_cast<const u32x2 *>(src + (N + c * NQ + tq) * 16 + hf * 8);
+                        // x-tiled: local column xl = 4 t + k -> slot SQ (k & 3) + t + (k >> 2); full width: x = 4 t - 2 + k
+                        // wrapped -> slot SQ ((k + 2) & 3) + (t - 1 | t | t + 1 mod NQT)
+                        const int sl = FULLW ? ((k + 2) & 3) * SQ + ((it_t + (k < 2 ? NQT - 1 : (k < 6 ? 0 : 1))) & (NQT - 1))
+                                             : (k & 3) * SQ + it_t + (k >> 2);
+                        raw[k][0] = *reinterpret_cast<const u32x2 *>(src + sl * 16 + hf * 8);
+                        raw[k][1] = *reinterpret_cast<const u32x2 *>(src + (PW + sl) * 16 + hf * 8);
                     }
                     float x[8][4];
 #pragma unroll
@@ -193,8 +213,8 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                             lw[e2] = pack_h2(mix_rest<0>(hw[e2], v0), mix_rest<1>(hw[e2], v1));
                         }
                         const u32x2 oh = {hw[0], hw[1]}, ol = {lw[0], lw[1]};
-                        *reinterpret_cast<u32x2 *>(dst + (size_t)q * PR * NQ * REC + uh + hf * 8) = oh;
-                        *reinterpret_cast<u32x2 *>(dst + (size_t)q * PR * NQ * REC + ul + hf * 8) = ol;
+                        *reinterpret_cast<u32x2 *>(dst + (size_t)q * PR * NQT * REC + uh + hf * 8) = oh;
+                        *reinterpret_cast<u32x2 *>(dst + (size_t)q * PR * NQT * REC + ul + hf * 8) = ol;
                     }
                 }
             }
@@ -208,10 +228,10 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
             }
             // the raw patch of the NEXT chunk (or of the next tile's first chunk) rides through this chunk's MFMA phase
+            // (one unit per thread and block, the remainder in the first / last block: load at the start of a block, store at
+            // its end.  Stores one block later cost 8-16 more live registers: spills, measured slower.)
             const bool more = ch + 1 < NCH || ti + 1 < n_my;
             const int n_tile = ch + 1 < NCH ? tile_g : tile_g + (int)gridDim.x, n_ch = ch + 1 < NCH ? ch + 1 : 0;
-            // (six units per thread: one per block, two in the last; load at the start of a block, store at its end.  Stores one
-            // block later, or at the start of the following block, cost 8-16 more live registers: spills, measured slower.)
             // ---- 5 row offsets x MT M-tiles x 2 output-channel tiles x 3 MFMAs ----
 #pragma unroll
             for (int ky = 0; ky < (EXP == 2 ? 0 : KY); ++ky) {
@@ -223,21 +243,27 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                     if (s == NCH * KY) s = 0;                  // the next tile starts over
                     if (EXP != 4) QGX_W_LOAD(s)
                 }
-                f32x4 rw0, rw1;                                // raw units ky (and 5 in the last block)
+                f32x4 rw0, rw1;
+                const bool two = (ky == KY - 1 && UPT > 5) || (ky == 0 && UPT > 6);
+                const int j1 = ky == 0 ? 6 : 5;
                 if (more && EXP != 5) {                        // AFTER the weight loads: vmcnt retires in order
-                    QGX_RAW_LOAD(ky, n_tile, n_ch, rw0)
-                    if (ky == KY - 1) QGX_RAW_LOAD(KY, n_tile, n_ch, rw1)
+                    if (ky < UPT) QGX_RAW_LOAD(ky, n_tile, n_ch, rw0)
+                    if (two) QGX_RAW_LOAD(j1, n_tile, n_ch, rw1)
                 }
                 __builtin_amdgcn_sched_barrier(0);             // hipcc otherwise sinks the prefetches to their use
                 h8 Pn[2];
-                Pn[0] = *reinterpret_cast<const h8 *>(vt + fbase + ky * NQ * REC);
-                Pn[1] = *reinterpret_cast<const h8 *>(vt + (fbase ^ 16) + ky * NQ * REC);
+                {
+                    const int f0 = frag(ky);
+                    Pn[0] = *reinterpret_cast<const h8 *>(vt + f0);
+                    Pn[1] = *reinterpret_cast<const h8 *>(vt + (f0 ^ 16));
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const h8 Ph = Pn[0], Pl = Pn[1];
                     if (mt + 1 < MT) {
-                        Pn[0] = *reinterpret_cast<const h8 *>(vt + fbase + ((mt + 1) * RM + ky) * NQ * REC);
-                        Pn[1] = *reinterpret_cast<const h8 *>(vt + (fbase ^ 16) + ((mt + 1) * RM + ky) * NQ * REC);
+                        const int f1 = frag((mt + 1) * RM + ky);
+                        Pn[0] = *reinterpret_cast<const h8 *>(vt + f1);
+                        Pn[1] = *reinterpret_cast<const h8 *>(vt + (f1 ^ 16));
                     }
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
@@ -247,13 +273,13 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                     }
                 }
                 if (more && EXP != 5) {
-                    QGX_RAW_STORE(ky, rw0)
-                    if (ky == KY - 1) QGX_RAW_STORE(KY, rw1)
+                    if (ky < UPT) QGX_RAW_STORE(ky, rw0)
+                    if (two) QGX_RAW_STORE(j1, rw1)
                 }
             }
         }
         // ---- output transform + epilogue, one M-tile at a time through the (now free) patch region ----
-        char *const ob = reinterpret_cast<char *>(a.out) + ((size_t)b * N + y0) * N * OPIXB;
+        char *const ob = reinterpret_cast<char *>(a.out) + (((size_t)b * N + y0) * N + x0) * OPIXB;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             __syncthreads();                                   // patch reads / previous staging reads are over
@@ -295,7 +321,7 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                     hw[e2] = pack_h2(v0, v1);
                     lw[e2] = pack_h2(mix_rest<0>(hw[e2], v0), mix_rest<1>(hw[e2], v1));
                 }
-                const int row = mt * RM + pl / NQ, col = 4 * (pl % NQ) + j;
+                const int row = mt * RM + pl / NQT, col = 4 * (pl % NQT) + j;
                 char *o = ob + ((size_t)row * N + col) * OPIXB + g * 32;
                 const u32x4 oh = {hw[0], hw[1], hw[2], hw[3]}, ol = {lw[0], lw[1], lw[2], lw[3]};
                 *reinterpret_cast<u32x4 *>(o) = oh;
@@ -306,4 +332,10 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
 #undef QGX_W_LOAD
 #undef QGX_RAW_LOAD
 #undef QGX_RAW_STORE
+}
+
+// LDS bytes of k_convw<NN, TW, R>
+constexpr size_t convw_lds_bytes(int NN, int TW, int R) {
+    const size_t vtb = (size_t)8 * (R + 4) * (TW / 4) * 64, st = (size_t)8 * 32 * (64 * 4 + 16);
+    return (vtb > st ? vtb : st) + (size_t)(R + 4) * 4 * (TW == NN ? NN : TW + 4) * 16 + (3 * 64 + 32) * sizeof(float);
 }
