@@ -141,7 +141,17 @@ def prof_stride(K):
     return 10 if K >= 1000 else (5 if K >= 200 else 2)
 
 
-def mfma_roofline(gen, precision, N, B, kname, traffic, stride=10):
+def layer2_kernel(gen, precision, N, B):
+    """(name of the kernel that runs generator layer 2 for this generator / shard, executed f16 MFMA flops per algorithmic flop)"""
+    if precision == 'f32':
+        return 'k_conv<128,64,5x5>', None
+    tiles = {32: 2, 48: 9, 64: 8, 96: 18, 128: 32}.get(N, 0) * B
+    if gen.wino_info()['enabled'] and tiles >= 128:
+        return 'k_convw (1-D Winograd F(4,5) along x, f16x3)', 3 * 0.4
+    return 'k_convh2<128,64,5x5> (25 taps, f16x3)', 3.0
+
+
+def mfma_roofline(gen, precision, N, B, kname, traffic, stride=10, executed_per_flop=3.0):
     """roofline object of the dominant kernel (generator layer 2: 75 % of the FLOPs) from the HIP events the
     library recorded around its launches inside the timed region"""
     ms, n = gen.profile_read()
@@ -156,9 +166,9 @@ def mfma_roofline(gen, precision, N, B, kname, traffic, stride=10):
          'peak_note': ('dense f32 MFMA peak; ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)' if precision == 'f32'
                        else 'dense f16 MFMA peak; `achieved` counts ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)')}
     if precision == 'f16x3':
-        r['mfma_pipe_frac'] = 3 * achieved / peak
-        r['mfma_pipe_note'] = ('f16x3 executes three f16 MFMAs per algorithmic multiply-add (hi*hi + hi*lo + lo*hi) to reach '
-                               'float32-class accuracy: executed MFMA flops = 3 x achieved')
+        r['mfma_pipe_frac'] = executed_per_flop * achieved / peak
+        r['mfma_pipe_note'] = ('f16x3 executes three f16 MFMAs per multiply-add (hi*hi + hi*lo + lo*hi); the 1-D Winograd form of the '
+                               f'5x5 layer multiplies 0.4 x as often as the 25-tap form: executed MFMA flops = {executed_per_flop:.1f} x achieved')
     return r
 
 
@@ -228,8 +238,9 @@ def leg_config3(qa, device, K=200, W=10):
     gen.set_option('prof_every', prof_stride(K))
     gen.profile(1)
     el = timed(lambda: loop.run(K))
-    roof = mfma_roofline(gen, 'f16x3', N, B, 'k_convh2<128,64,5x5> at 96x96 (generator layer 2)',
-                         pmc_traffic('pmc_traffic_config3.json', {'nx': N, 'members_per_gpu': B, 'kind': 'vae'}), prof_stride(K))
+    kn, ex = layer2_kernel(gen, 'f16x3', N, B)
+    roof = mfma_roofline(gen, 'f16x3', N, B, kn + ' at 96x96 (generator layer 2)',
+                         pmc_traffic('pmc_traffic_config3.json', {'nx': N, 'members_per_gpu': B, 'kind': 'vae'}), prof_stride(K), ex)
     ke, cfl = eng.status()
     out = {'workload': f'BASELINE configs[3] shard: jet {N}x{N} + CVAE, {B} members on 1 GPU (256 members / 8 GPUs), '
                        f"sampling='constant' nsteps=1, dt={dt:.0f}s",
@@ -320,7 +331,8 @@ def leg_members(qa, device, gen, B, K, W, name, note):
            'ms_per_step': 1e3 * el / K, 'snapshots_in_timed_region': loop.nsnap - n0[0],
            'status_checks_in_timed_region': loop.nstatus - n0[1]}
     if B >= 8:
-        out['roofline'] = mfma_roofline(gen, 'f16x3', N, B, 'k_convh2<128,64,5x5> (generator layer 2)', None, prof_stride(K))
+        kn, ex = layer2_kernel(gen, 'f16x3', N, B)
+        out['roofline'] = mfma_roofline(gen, 'f16x3', N, B, kn + ' (generator layer 2)', None, prof_stride(K), ex)
     else:
         gen.profile_read()
         gen.profile(-1)
@@ -420,18 +432,19 @@ def main():
     healthy = bool(np.isfinite(ke).all() and (cfl < 1).all())
 
     out = None
-    kname = ('k_conv<128,64,5x5>' if args.precision == 'f32' else 'k_convh2<128,64,5x5>') + ' (generator layer 2)'
+    kname, executed = layer2_kernel(gen, args.precision, N, B)
+    kname += ' (generator layer 2)'
     cfg = {'nx': N, 'members_per_gpu': B, 'kind': args.kind}
     traffic = {'f32': pmc_traffic('pmc_traffic.json', cfg), 'f16x3': pmc_traffic('pmc_traffic_f16x3.json', cfg)}[args.precision]
     gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
     if rank == 0:
         value = total_members * K / elapsed
-        roof = mfma_roofline(gen, args.precision, N, B, kname, traffic, stride)
+        roof = mfma_roofline(gen, args.precision, N, B, kname, traffic, stride, executed or 3.0)
         roof['whole_step_generator_tflops'] = gen_flop_per_member_step * value / world / 1e12
         dtype = {'f32': 'f64 spectral core + f32 generator (exact-f32 MFMA)',
-                 'f16x3': 'f64 spectral core + f32-class generator: f16 hi/lo split operands, 3 f16 MFMAs per '
-                          'product, f32 accumulate (error vs a float64 ground truth <= the exact-f32 path, '
-                          'tests/test_gpu_precision.py)'}[args.precision]
+                 'f16x3': 'f64 spectral core + generator in f16 hi/lo split operands, 3 f16 MFMAs per product, f32 accumulate '
+                          '(25-tap kernels: float32 error class; the 5x5 layer as a 1-D Winograd convolution where calibration '
+                          'admitted it: within 1e-5 of the exact-f32 kernels, golden-vector tolerance 2e-5; tests/test_gpu_precision.py)'}[args.precision]
         shard = (f'ONE {total_members}-member ensemble split over {world} GPU(s): {B} members on rank 0' if strong else
                  f'{B} members per GPU (BASELINE configs[2] shard: 1024 members / 8 GPUs)')
         out = {
@@ -463,7 +476,7 @@ def main():
         gen.profile(1)
         n0 = (loop.nsnap, loop.nstatus)
         els = timed(lambda: loop.run(KS))
-        rs = mfma_roofline(gen, args.precision, N, B, kname, traffic, 10)
+        rs = mfma_roofline(gen, args.precision, N, B, kname, traffic, 10, executed or 3.0)
         vs = B * KS / els
         rs['whole_step_generator_tflops'] = gen_flop_per_member_step * vs / 1e12
         out['steady'] = {'protocol': 'SURVEY 8(d): 100 warm-up + 2000 timed steps at the reference cadences, independent of --steps',
