@@ -1773,7 +1773,7 @@ static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, 
 
 template <int NIN>
 static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float *in, void *out, int B, int N,
-                              hipStream_t st) {
+                              hipStream_t st, bool wino_next = false) {
     int R = choose_rows(N);
     QGX_REQUIRE(R > 0 && N % R == 0 && N % 4 == 0, "generator: unsupported grid size N=%d", N);
     // one 8-wave workgroup per CU with double-height tiles where two M-tiles per wave result (64 x 64, 32 x 32) and
@@ -1794,6 +1794,7 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
     a.stamps = g->stamp_layer == 0 ? g->stamps : nullptr;
     a.in = in; a.out = out; a.w = L.whf; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
     a.unscale = L.whf_unscale; a.ascale = g->opt_ascale; a.N = N; a.R = R;
+    a.guard_mul = wino_next ? 16.f : 1.f;
     a.range = g->range_dev; a.range_bit = 1u;
     const int total_tiles = B * (N / R);
     const int wgs = lds * 2 <= 160 * 1024 ? 2 : 1;
@@ -1892,7 +1893,11 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
             L1.wh[1] = L1.whF; L1.wh_unscale[1] = L1.whF_unscale; L1.bias = L1.biasF; L1.wh16 = L1.wh16F;
         }
         if (NS == 2 && g->opt_first_h) {
-            rc = net.n_in == 4 ? launch_convh_first<4>(g, L0, xc, A, Bc, N, st) : launch_convh_first<2>(g, L0, xc, A, Bc, N, st);
+            // (will the 5x5 layer run as the Winograd form?  then layer 1's range guard covers its input transform too)
+            const int r2w = rows_h2(N);
+            const bool wino_next = NS == 2 && g->opt_wino && net.L[1].ww[0] && wino_tiles(Bc, N) >= g->opt_wino_min_tiles &&
+                                   !(g->opt_h2 == 3 && r2w > 0 && Bc * (N / r2w) < g->opt_part_max_tiles);
+            rc = net.n_in == 4 ? launch_convh_first<4>(g, L0, xc, A, Bc, N, st, wino_next) : launch_convh_first<2>(g, L0, xc, A, Bc, N, st, wino_next);
         } else if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         if (rc) return rc;

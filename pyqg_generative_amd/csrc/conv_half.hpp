@@ -91,10 +91,12 @@ __device__ __forceinline__ unsigned pack_h2(float a, float b) {
 
 // Epilogue of one 32(out channels) x 32(pixels) accumulator tile in the swapped-role layout:
 // lane (li, h) owns pixel li; register r holds output channel cb + (r & 3) + 8 (r >> 2) + 4 h.
+// guard_mul: the consumer's amplification of the stored values before ITS 16-bit split (the Winograd layer's input
+// transform: up to 16) — the guard then fires at 65504 / guard_mul
 template <int NS, bool OUTF32>
 __device__ __forceinline__ void store_tile_t(const f32x16 &acc, int cb, int h, char *pix, const float *bias,
                                              const float *scale, const float *shift, float unscale, float ascale,
-                                             unsigned *range, unsigned range_bit) {
+                                             unsigned *range, unsigned range_bit, float guard_mul = 1.f) {
     float v[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -115,7 +117,7 @@ __device__ __forceinline__ void store_tile_t(const f32x16 &acc, int cb, int h, c
         float mx = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(v[e]));
-        range_guard(mx * ascale, range, range_bit);
+        range_guard(mx * ascale * guard_mul, range, range_bit);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             float hi[8], lo[8];
@@ -772,6 +774,7 @@ struct ConvHFirstArgs {
     const void *w;         // [step][part][h][128][8] f16
     const float *bias, *scale, *shift;
     float unscale, ascale;
+    float guard_mul;       // 16 when the 5x5 layer behind it is the Winograd form (its input transform amplifies by <= 15)
     int N, R;
     unsigned long long *stamps;   // diagnostic builds only
     unsigned *range;       // range guard flag word, bit of this layer (see range_guard)
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
         const int tile = wave + NW * mt;
         if (tile >= ntiles) return;
         char *pix = obase + (size_t)(tile * 32 + li) * (COUT * 4);
-        store_tile_t<2, false>(ac[mt][nt], half_of * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit);
+        store_tile_t<2, false>(ac[mt][nt], half_of * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit, a.guard_mul);
     };
     for (int ti = 0; ti < n_my; ++ti) {
         const bool have_next = ti + 1 < n_my;

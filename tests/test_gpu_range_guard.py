@@ -182,3 +182,35 @@ def test_runtime_guard_catches_an_overflow_and_recovers():
     e.step(3, generator=gen3, sampling='constant', nsteps_decor=1, seed=1)
     ke, cfl = e.status()
     assert np.isfinite(ke).all()
+
+
+def test_guard_covers_the_winograd_input_transform():
+    """the 1-D Winograd form of the 5x5 layer amplifies its input by up to 15 before the 16-bit split: a layer-1 activation
+    that is still inside the f16 range when stored can leave it in the transform, and behind a ReLU the resulting inf / NaN
+    would become an innocent zero.  Layer 1's guard (flag bit 0) therefore fires at 65504 / 16 when the Winograd layer
+    follows it: an input scale that puts layer 1's largest stored value at ~6e3 raises bit 0 with the Winograd layer and
+    not with the 25-tap layer (deeper layers overflow at that scale either way; the stand-alone call recovers on the
+    exact-f32 kernels as for any other flag)."""
+    import pyqg_generative_amd as qa
+    nets, xs, ys = _shipped('gan')
+    gen = qa.Generator('gan', nets, xs, ys)
+    stored = gen.info()['layer_absmax'][8]                 # layer 1 before its BatchNorm: what the folded variant stores
+    assert gen.info()['fold'] == 1 and stored > 0
+    N, B = 64, 16
+    x = _inputs(B, N, seed=9)
+    mult = 6000.0 / stored                                 # between 65504 / 16 and 65504
+    xd = torch.as_tensor(x * mult, device='cuda')
+    gen.check_range = False
+    flags = {}
+    for wino in (0, 1):
+        gen.set_option('wino', wino)
+        gen.cnn_forward(xd)
+        flags[wino], _ = gen.range_read()
+    assert flags[1] & 1 and not flags[0] & 1, flags
+    truth = gen_ref.cnn_forward(_oracle(nets[0]), (x * mult)[:2], dtype='float64')
+    gen.check_range = True
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        y = gen.cnn_forward(xd).cpu().numpy()
+    assert any('exact-f32' in str(i.message) for i in w)
+    assert _maxrel(y[:2], truth) < 2e-5
