@@ -112,10 +112,10 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
     for (int i = threadIdx.x; i < 3 * COUT + 32; i += 512)
         ep[i] = i < COUT ? a.bias[i] : (i < 2 * COUT ? a.scale[i - COUT] : (i < 3 * COUT ? a.shift[i - 2 * COUT] : a.atp[(i - 3 * COUT) >> 3][(i - 3 * COUT) & 7]));
 
-    // transform item of this thread: lanes run over the quads first (consecutive slots of the raw patch)
-    const int it_t = threadIdx.x % NQT, it_o = (threadIdx.x / NQT) & 1, it_r = threadIdx.x / (2 * NQT);
-    const bool has_item = threadIdx.x < NITEM;
-    const int it_sw = ((it_r * NQT + it_t) >> 2) & 3;
+    // transform work items: (row, quad, octet, half of the octet's 8 channels); lanes run over the quads first (consecutive
+    // slots of the raw patch).  NHALF = 2 NITEM half-items over 512 threads in two rounds: at 64 x 64 waves 0..3 take two,
+    // waves 4..7 one, i.e. 1.5 item-times per SIMD (whole items on waves 0..5 made it 2 on SIMDs 0 and 1)
+    constexpr int NHALF = 2 * NITEM;
     // B fragment of this lane: pair li = (row li / NQT, quad li % NQT) of an M-tile, octet h (units 2h | 2h + 1, swizzled)
     const int fq = li % NQT, fr = li / NQT;
     const int fbase = ((p * PR + fr) * NQT + fq) * REC + (((2 * h) ^ (((fr * NQT + fq) >> 2) & 3)) * 16);
@@ -177,13 +177,15 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
         for (int ch = 0; ch < NCH; ++ch) {
             // ---- input transform of this chunk: raw patch (LDS) -> float32 BT -> hi / lo -> transformed patch (LDS) ----
             __syncthreads();        // the raw patch has landed; every wave is done reading the previous transformed patch
-            if (has_item && EXP != 1) {
-                const char *src = rawb + (size_t)(it_r * 4 + it_o * 2) * PW * 16;
-                char *dst = vt + ((size_t)it_r * NQT + it_t) * REC;
-                const int uh = ((2 * it_o) ^ it_sw) * 16, ul = uh ^ 16;
-                // two halves of 4 channels: the tile's 128 accumulators stay live, which leaves ~100 registers here
 #pragma nounroll
-                for (int hf = 0; hf < 2; ++hf) {
+            for (int rep = 0; rep < (NHALF + 511) / 512; ++rep) {
+                const int hi_ = rep * 512 + (int)threadIdx.x;
+                if (hi_ < NHALF && EXP != 1) {
+                    const int it_t = hi_ % NQT, it_o = (hi_ / NQT) & 1, hf = (hi_ / (2 * NQT)) & 1, it_r = hi_ / (4 * NQT);
+                    const int it_sw = ((it_r * NQT + it_t) >> 2) & 3;
+                    const char *src = rawb + (size_t)(it_r * 4 + it_o * 2) * PW * 16;
+                    char *dst = vt + ((size_t)it_r * NQT + it_t) * REC;
+                    const int uh = ((2 * it_o) ^ it_sw) * 16, ul = uh ^ 16;
                     u32x2 raw[8][2];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -228,10 +230,9 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                         for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
             }
             // the raw patch of the NEXT chunk (or of the next tile's first chunk) rides through this chunk's MFMA phase
-            // (one unit per thread and block, the remainder in the first / last block: load at the start of a block, store at
-            // its end.  Stores one block later cost 8-16 more live registers: spills, measured slower.)
             const bool more = ch + 1 < NCH || ti + 1 < n_my;
             const int n_tile = ch + 1 < NCH ? tile_g : tile_g + (int)gridDim.x, n_ch = ch + 1 < NCH ? ch + 1 : 0;
+            f32x4 rw0, rw1;
             // ---- 5 row offsets x MT M-tiles x 2 output-channel tiles x 3 MFMAs ----
 #pragma unroll
             for (int ky = 0; ky < (EXP == 2 ? 0 : KY); ++ky) {
@@ -243,12 +244,13 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                     if (s == NCH * KY) s = 0;                  // the next tile starts over
                     if (EXP != 4) QGX_W_LOAD(s)
                 }
-                f32x4 rw0, rw1;
-                const bool two = (ky == KY - 1 && UPT > 5) || (ky == 0 && UPT > 6);
-                const int j1 = ky == 0 ? 6 : 5;
+                // raw copy, two units per thread at a time: loaded in blocks 0, 2 and 4, stored at the END of blocks 1, 3 and 4 —
+                // two blocks (~1.6 us) of flight for four of the six units instead of one for all of them (a store at the
+                // end of the block that issued the load made the wave wait out the HBM latency there); the same 8 registers
                 if (more && EXP != 5) {                        // AFTER the weight loads: vmcnt retires in order
-                    if (ky < UPT) QGX_RAW_LOAD(ky, n_tile, n_ch, rw0)
-                    if (two) QGX_RAW_LOAD(j1, n_tile, n_ch, rw1)
+                    if (ky == 0) { QGX_RAW_LOAD(0, n_tile, n_ch, rw0) if (UPT > 1) QGX_RAW_LOAD(1, n_tile, n_ch, rw1) }
+                    if (ky == 2 && UPT > 2) { QGX_RAW_LOAD(2, n_tile, n_ch, rw0) if (UPT > 3) QGX_RAW_LOAD(3, n_tile, n_ch, rw1) }
+                    if (ky == 4 && UPT > 4) { QGX_RAW_LOAD(4, n_tile, n_ch, rw0) if (UPT > 5) QGX_RAW_LOAD(5, n_tile, n_ch, rw1) }
                 }
                 __builtin_amdgcn_sched_barrier(0);             // hipcc otherwise sinks the prefetches to their use
                 h8 Pn[2];
@@ -273,8 +275,10 @@ __global__ __launch_bounds__(512) void k_convw(ConvWArgs a, int total_tiles) {
                     }
                 }
                 if (more && EXP != 5) {
-                    if (ky < UPT) QGX_RAW_STORE(ky, rw0)
-                    if (two) QGX_RAW_STORE(j1, rw1)
+                    if (ky == 1) { QGX_RAW_STORE(0, rw0) if (UPT > 1) QGX_RAW_STORE(1, rw1) }
+                    if (ky == 3 && UPT > 2) { QGX_RAW_STORE(2, rw0) if (UPT > 3) QGX_RAW_STORE(3, rw1) }
+                    if (ky == 4 && UPT > 4) { QGX_RAW_STORE(4, rw0) if (UPT > 5) QGX_RAW_STORE(5, rw1) }
+                    if (ky == 4 && UPT > 6) { f32x4 rw2; QGX_RAW_LOAD(6, n_tile, n_ch, rw2) QGX_RAW_STORE(6, rw2) }
                 }
             }
         }
