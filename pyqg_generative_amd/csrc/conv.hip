@@ -840,6 +840,7 @@ struct qgx_generator {
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
     int opt_half_min_tiles = 1;
+    int opt_pair_lp = 1;           // A/B library only: 0 = the pair kernels fetch the two halves of a line in different chunk iterations
     int opt_fuse = 3;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
     int opt_pair = 1;              // 3x3 k_convh2: fetch both 64-byte halves of a pixel's 128-byte line together
     int opt_h2 = 3;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
@@ -1764,6 +1765,9 @@ static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, 
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
     auto kern = k_convh_pair<CINA, NN, LAST, BOUTF32>;
+#ifdef QGX_AB
+    if (!g->opt_pair_lp) kern = k_convh_pair<CINA, NN, LAST, BOUTF32, false>;
+#endif
     { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
     QGX_HIP(hipGetLastError());
@@ -2371,6 +2375,9 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "h2")) g->opt_h2 = value & 3;
     else if (!strcmp(name, "pair")) g->opt_pair = value ? 1 : 0;
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
+#ifdef QGX_AB
+    else if (!strcmp(name, "pair_lp")) g->opt_pair_lp = value;
+#endif
     else if (!strcmp(name, "h3")) g->opt_h3 = value ? 1 : 0;
     else if (!strcmp(name, "last_rows")) g->opt_last_rows = value;
     else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;

@@ -32,7 +32,7 @@ struct ConvPairArgs {
     unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only
 };
 
-template <int CINA, int NN, bool LAST, bool BOUTF32>
+template <int CINA, int NN, bool LAST, bool BOUTF32, bool LP = (CINA == 32)>
 __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_tiles) {
     constexpr int NW = 8, NTHR = 512, N = NN, R = 8, T = 9;
     constexpr int NCA = CINA / 16;
@@ -129,9 +129,15 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
         epA[i] = i < 32 ? a.biasA[i] : (i < 64 ? a.scaleA[i - 32] : a.shiftA[i - 64]);
         epB[i] = i < 32 ? a.biasB[i] : (i < 64 ? a.scaleB[i - 32] : a.shiftB[i - 64]);
     }
+    // LP (two input chunks = the two 64-byte halves of a pixel's 128-byte line): fetching the halves in different
+    // chunk iterations brought every line from HBM twice (FETCH_SIZE 178 MB for a 100 MB halo-amplified input), so
+    // both halves of the NEXT tile are loaded together during phase B and the second waits in registers for its turn
+    static_assert(!LP || NCA == 2, "line-pair prefetch: two chunks");
+    f32x4 pvB[LP ? PPT : 1];
     {
         f32x4 pv[PPT], wv[WPT], wtmp[(WB_BYTES / 16 + NTHR - 1) / NTHR];
         QGX_PP_LOAD(0, 0, pv)
+        if constexpr (LP) QGX_PP_LOAD(0, 1, pvB)
         QGX_PW_LOAD(0, wv)
         QGX_BULK_LOAD(wtmp, a.wB, WB_BYTES / 16, NTHR)
         QGX_PP_STORE(pv)
@@ -173,7 +179,7 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
         for (int ch = 0; ch < NCA; ++ch) {
             f32x4 pv[PPT], wv[WPT];
             // the global prefetch loads of this chunk are spread over its first taps (see k_convh2)
-            const int n_ld = WPT + (ch + 1 < NCA ? PPT : 0);
+            const int n_ld = WPT + (!LP && ch + 1 < NCA ? PPT : 0);
             h8 Pn[MTA][2], Wn[2];
 #define QGX_PA_FRAGS(TAP)                                                                                   \
             {                                                                                               \
@@ -215,7 +221,7 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
             QGX_STAMP()
             QGX_PW_STORE(wv)
             if (ch + 1 < NCA) {
-                QGX_PP_STORE(pv)
+                if constexpr (LP) { QGX_PP_STORE(pvB) } else { QGX_PP_STORE(pv) }
             } else {
                 // ---- layer A epilogue into the intermediate patch (region shared with the input chunk)
 #pragma unroll
@@ -305,9 +311,18 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
                 for (int mt = 0; mt < MTB; ++mt) { Pc[mt][0] = Pn[mt][0]; Pc[mt][1] = Pn[mt][1]; }
                 Wc[0] = Wn[0]; Wc[1] = Wn[1];
                 if (s + 1 < 2 * T) QGX_PB_FRAGS(s + 1)
+                if constexpr (LP) {
 #pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if ((i * (2 * T - 2)) / PPT == s) QGX_PP_LOAD1(have_next_tile ? ti + 1 : ti, 0, pv, i)
+                    for (int i = 0; i < 2 * PPT; ++i)
+                        if ((i * (2 * T - 2)) / (2 * PPT) == s) {
+                            if (i & 1) { QGX_PP_LOAD1(have_next_tile ? ti + 1 : ti, 1, pvB, i >> 1) }
+                            else { QGX_PP_LOAD1(have_next_tile ? ti + 1 : ti, 0, pv, i >> 1) }
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < PPT; ++i)
+                        if ((i * (2 * T - 2)) / PPT == s) QGX_PP_LOAD1(have_next_tile ? ti + 1 : ti, 0, pv, i)
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MTB; ++mt) {
