@@ -8,7 +8,7 @@ import bench
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 N = 64
-for kind in ('gan', 'vae', 'gz'):
+for kind in (('gan', 'vae', 'gz') if len(sys.argv) < 3 else sys.argv[2:]):
     gen, _ = bench.load_generator(kind, 0)
     gen.check_range = False
     rs = np.random.RandomState(1)
@@ -20,8 +20,11 @@ for kind in ('gan', 'vae', 'gz'):
     ref = gen.cnn_forward(xd).double()
     gen.set_option('precision', 3)
     out = {}
-    for wino in (0, 1):
-        gen.set_option('wino', wino)
+    ab = b'+ab' in __import__('pyqg_generative_amd')._lib.lib.qgx_version()
+    for wino in ((0, 1, 2) if ab else (0, 1)):
+        gen.set_option('wino', 1 if wino else 0)
+        if ab:
+            gen.set_option('wino_pl', 1 if wino == 2 else 0)     # 2: channel-planar layer 1 + MFMA input transform (A/B only)
         gen.set_option('wino_min_tiles', 1)
         y = gen.cnn_forward(xd)
         torch.cuda.synchronize()
@@ -35,8 +38,9 @@ for kind in ('gan', 'vae', 'gz'):
         err = float((out[wino] - ref).abs().max() / ref.abs().max())
         print(f'{kind} B={B} wino={wino}: max |y - y_f32| / max|y| = {err:.2e}; layer 2 {1e3 * ms / max(n, 1):.1f} us; flags {gen.range_read()}', flush=True)
     print(f'   wino vs 25-tap: {float((out[1] - out[0]).abs().max() / ref.abs().max()):.2e}')
-    if b'+ab' in __import__('pyqg_generative_amd')._lib.lib.qgx_version():
-        for exp, what in ((2, 'no MFMAs'), (4, 'weights loaded once'), (5, 'no raw-patch copy')):
+    if ab:
+        gen.set_option('wino_pl', 0)
+        for exp, what in ((2, 'no MFMAs'), (4, 'weights loaded once'), (5, 'no raw-patch copy'), (1, 'no input transform'), (6, 'no output stores'), (7, 'no MFMAs, no input transform'), (8, 'no MFMAs, no output stores')):
             gen.set_option('wino_exp', exp)
             gen.cnn_forward(xd)
             gen.profile(1)

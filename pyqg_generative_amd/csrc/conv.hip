@@ -833,6 +833,8 @@ struct qgx_generator {
     int opt_wino = 1;              // f16x3, 64 x 64: the 5x5 layer as a 1-D Winograd convolution F(4, 5) along x (k_convw)
     int auto_wino = 0;             //   ... what calibrate_wino() decided, and the error it measured for it
     float wino_err = 0.f;
+    int opt_stop_layer = 0;        //   A/B library, debugging: return after this many layers (the activation buffers keep their outputs)
+    int opt_wino_pl = 0;           //   A/B library: 1 = channel-planar layer-1 output and the MFMA input transform (measured: see wino_planar)
     int opt_wino_exp = 0;          //   A/B library: timing experiments (conv_wino.hpp EXP)
     int opt_wino_min_tiles = 128;  //   ... from this many 8-row tiles on (below it the persistent workgroups do not fill the CUs)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
@@ -962,7 +964,7 @@ static const double WINO_G[8][5] = {{-1, 0, 0, 0, 0},
                                     {32. / 45, 16. / 45, 8. / 45, 4. / 45, 2. / 45},
                                     {32. / 45, -16. / 45, 8. / 45, -4. / 45, 2. / 45},
                                     {0, 0, 0, 0, 1}};
-static const float WINO_AT[4][8] = {{1, 1, 1, 1, 1, 1, 1, 0},
+[[maybe_unused]] static const float WINO_AT[4][8] = {{1, 1, 1, 1, 1, 1, 1, 0},
                                     {0, 1, -1, 2, -2, .5f, -.5f, 0},
                                     {0, 1, 1, 4, 4, .25f, .25f, 0},
                                     {0, 1, -1, 8, -8, .125f, -.125f, 1}};
@@ -1777,7 +1779,7 @@ static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, 
 
 template <int NIN>
 static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float *in, void *out, int B, int N,
-                              hipStream_t st, bool wino_next = false) {
+                              hipStream_t st, bool wino_next = false, bool planar = false) {
     int R = choose_rows(N);
     QGX_REQUIRE(R > 0 && N % R == 0 && N % 4 == 0, "generator: unsupported grid size N=%d", N);
     // one 8-wave workgroup per CU with double-height tiles where two M-tiles per wave result (64 x 64, 32 x 32) and
@@ -1804,9 +1806,14 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
     const int wgs = lds * 2 <= 160 * 1024 ? 2 : 1;
     int grid = 256 * wgs;
     if (grid > total_tiles) grid = total_tiles;
+#ifdef QGX_AB
+#define QGX_LF_KERN(MTV, PPTV, NWV) (planar ? k_convh_first<NIN, MTV, PPTV, NWV, true> : k_convh_first<NIN, MTV, PPTV, NWV, false>)
+#else
+#define QGX_LF_KERN(MTV, PPTV, NWV) k_convh_first<NIN, MTV, PPTV, NWV, false>
+#endif
 #define QGX_LF(MTV, PPTV, NWV)                                                                                \
     {                                                                                                         \
-        auto kern = k_convh_first<NIN, MTV, PPTV, NWV>;                                                       \
+        auto kern = QGX_LF_KERN(MTV, PPTV, NWV);                                                              \
         { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; } \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, a, total_tiles);                        \
     }
@@ -1814,33 +1821,36 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
     else if (ntiles == 8) { if (ppt <= 2) QGX_LF(2, 2, 4) else QGX_LF(2, 3, 4) }
     else { if (ppt <= 2) QGX_LF(3, 2, 4) else QGX_LF(3, 3, 4) }
 #undef QGX_LF
+#undef QGX_LF_KERN
     QGX_HIP(hipGetLastError());
     if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
     return QGX_OK;
 }
 
 // layer 2 as a 1-D Winograd convolution (conv_wino.hpp); done = false: no specialisation for this grid / ensemble size
-template <int NN, int TW, int R>
+template <int NN, int TW, int R, bool PL = false>
 static int launch_convw_n(qgx_generator *g, int layer, const LayerHost &L, int which, const void *in, void *out, int B,
                           hipStream_t st) {
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, layer, st, prof_stop); if (prc) return prc; }
     ConvWArgs a = {};
     a.in = in; a.out = out; a.w = L.ww[which]; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
-    for (int j = 0; j < 4; ++j)
-        for (int p = 0; p < 8; ++p) a.atp[j][p] = WINO_AT[j][p] * L.ww_unscale[which][p] / g->opt_ascale;
+    for (int p = 0; p < 8; ++p) a.pscale[p] = L.ww_unscale[which][p] / g->opt_ascale;
     a.ascale = g->opt_ascale;
     a.range = g->range_dev; a.range_bit = 1u << layer;
     const int total_tiles = B * (NN / R) * (NN / TW);
-    constexpr size_t lds = convw_lds_bytes(NN, TW, R);
+    constexpr size_t lds = convw_lds_bytes(NN, TW, R, PL);
     static_assert(lds <= 160 * 1024 - 256, "k_convw: LDS");
     const int grid = total_tiles < 256 ? total_tiles : 256;
-    void (*kern)(ConvWArgs, int) = k_convw<NN, TW, R>;
+    void (*kern)(ConvWArgs, int) = k_convw<NN, TW, R, 0, PL>;
 #ifdef QGX_AB       // timing experiments: parts of the kernel switched off (wrong results)
-    if (g->opt_wino_exp == 1) kern = k_convw<NN, TW, R, 1>;
-    else if (g->opt_wino_exp == 2) kern = k_convw<NN, TW, R, 2>;
-    else if (g->opt_wino_exp == 4) kern = k_convw<NN, TW, R, 4>;
-    else if (g->opt_wino_exp == 5) kern = k_convw<NN, TW, R, 5>;
+    if (g->opt_wino_exp == 1) kern = k_convw<NN, TW, R, 1, PL>;
+    else if (g->opt_wino_exp == 2) kern = k_convw<NN, TW, R, 2, PL>;
+    else if (g->opt_wino_exp == 4) kern = k_convw<NN, TW, R, 4, PL>;
+    else if (g->opt_wino_exp == 5) kern = k_convw<NN, TW, R, 5, PL>;
+    else if (g->opt_wino_exp == 6) kern = k_convw<NN, TW, R, 6, PL>;
+    else if (g->opt_wino_exp == 7) kern = k_convw<NN, TW, R, 7, PL>;
+    else if (g->opt_wino_exp == 8) kern = k_convw<NN, TW, R, 8, PL>;
 #endif
     { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
@@ -1859,12 +1869,42 @@ static int wino_tiles(int B, int N) {
         default: return 0;
     }
 }
+// does the 5x5 layer run as the Winograd form for this ensemble?  (decided BEFORE layer 1: its output layout — channel-planar
+// for the MFMA input transform — and its range guard depend on it)
+static bool wino_applies(const qgx_generator *g, const LayerHost &L, int which, int B, int N) {
+    const int tiles = wino_tiles(B, N);
+    return g->opt_wino && L.ww[which] && tiles > 0 && tiles >= g->opt_wino_min_tiles;
+}
+// A/B library only: layer 1 stores channel-planar rows and the Winograd layer's input transform runs on the matrix cores
+// (conv_wino.hpp PL).  Measured against the product's pixel-major form (bench_tools/ab_conv.py, wino_pl): 64 x 64 / 128 members
+// -3 us on layer 2 and -2...-4 us on layer 1 of 370; 96 x 96 302 vs 206 us, 128 x 128 230 vs 153 us (8-pixel octets make the x halo of
+// the column-tiled shapes 1.33x, and the kernels spill) — not in the product.
+static bool wino_planar(const qgx_generator *g) {
+#ifdef QGX_AB
+    return g->opt_wino_pl != 0;
+#else
+    (void)g;
+    return false;
+#endif
+}
 static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int which, const void *in, void *out, int B, int N,
                         hipStream_t st, bool &done) {
     done = false;
-    const int tiles = wino_tiles(B, N);
-    if (!g->opt_wino || !L.ww[which] || tiles == 0 || tiles < g->opt_wino_min_tiles) return QGX_OK;
+    if (!wino_applies(g, L, which, B, N)) return QGX_OK;
     int rc;
+#ifdef QGX_AB
+    if (wino_planar(g)) {
+        switch (N) {
+            case 32: rc = launch_convw_n<32, 32, 16, true>(g, layer, L, which, in, out, B, st); break;
+            case 48: rc = launch_convw_n<48, 16, 16, true>(g, layer, L, which, in, out, B, st); break;
+            case 64: rc = launch_convw_n<64, 64, 8, true>(g, layer, L, which, in, out, B, st); break;
+            case 96: rc = launch_convw_n<96, 32, 16, true>(g, layer, L, which, in, out, B, st); break;
+            default: rc = launch_convw_n<128, 32, 16, true>(g, layer, L, which, in, out, B, st); break;   // (64-column tiles: raw + transformed patch > 160 KB)
+        }
+        if (!rc) done = true;
+        return rc;
+    }
+#endif
     switch (N) {
         case 32: rc = launch_convw_n<32, 32, 16>(g, layer, L, which, in, out, B, st); break;
         case 48: rc = launch_convw_n<48, 16, 16>(g, layer, L, which, in, out, B, st); break;
@@ -1896,22 +1936,30 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
             L0.scale = L0.ones; L0.shift = L0.zeros;
             L1.wh[1] = L1.whF; L1.wh_unscale[1] = L1.whF_unscale; L1.bias = L1.biasF; L1.wh16 = L1.wh16F;
         }
+        bool wino2 = false;
         if (NS == 2 && g->opt_first_h) {
             // (will the 5x5 layer run as the Winograd form?  then layer 1's range guard covers its input transform too)
             const int r2w = rows_h2(N);
-            const bool wino_next = NS == 2 && g->opt_wino && net.L[1].ww[0] && wino_tiles(Bc, N) >= g->opt_wino_min_tiles &&
-                                   !(g->opt_h2 == 3 && r2w > 0 && Bc * (N / r2w) < g->opt_part_max_tiles);
-            rc = net.n_in == 4 ? launch_convh_first<4>(g, L0, xc, A, Bc, N, st, wino_next) : launch_convh_first<2>(g, L0, xc, A, Bc, N, st, wino_next);
+            wino2 = NS == 2 && wino_applies(g, L1, fold ? 1 : 0, Bc, N) &&
+                    !(g->opt_h2 == 3 && r2w > 0 && Bc * (N / r2w) < g->opt_part_max_tiles);
+            rc = net.n_in == 4 ? launch_convh_first<4>(g, L0, xc, A, Bc, N, st, wino2, wino2 && wino_planar(g))
+                               : launch_convh_first<2>(g, L0, xc, A, Bc, N, st, wino2, wino2 && wino_planar(g));
         } else if (net.n_in == 4) rc = launch_conv<4, 128, 5, 4, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         else rc = launch_conv<2, 128, 5, 2, true, false, 2, NS>(g, 0, net.L[0], xc, A, Bc, N, 128, st);
         if (rc) return rc;
+#ifdef QGX_AB
+        if (g->opt_stop_layer == 1) return QGX_OK;
+#endif
         // single members / tiny ensembles (fewer than "part_max_tiles" tiles): split K on the two wide layers and
         // do not fuse (7, 8) (8 tiles of 512 pixels would leave 248 CUs idle)
         const int r2 = rows_h2(N);
         const bool tiny = NS == 2 && g->opt_h2 == 3 && r2 > 0 && Bc * (N / r2) < g->opt_part_max_tiles;
         bool done1 = false;
         if (tiny && (rc = launch_convh2_part<128, 64, 5, false>(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
-        if (!done1 && NS == 2 && (rc = launch_convw(g, 1, L1, fold ? 1 : 0, A, Bb, Bc, N, st, done1))) return rc;
+        if (!done1 && wino2) {
+            if ((rc = launch_convw(g, 1, L1, fold ? 1 : 0, A, Bb, Bc, N, st, done1))) return rc;
+            QGX_REQUIRE(done1, "generator: layer 1 was stored for the Winograd layer, which did not run (N=%d)", N);
+        }
 #ifdef QGX_AB
         if (!done1 && NS == 2 && g->opt_h4 && (rc = launch_convh4(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
         if (!done1 && NS == 2 && g->opt_h3 && (rc = launch_convh3(g, 1, L1, A, Bb, Bc, N, st, done1))) return rc;
@@ -1921,6 +1969,9 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         if (!done1 && (rc = launch_convh<128, 64, 5, NS, false>(g, 1, L1, A, Bb, Bc, N, st))) return rc;
 #else
         QGX_REQUIRE(done1, "generator: no f16x3 kernel for N=%d", N);
+#endif
+#ifdef QGX_AB
+        if (g->opt_stop_layer == 2) return QGX_OK;
 #endif
         if (tiny) {
             bool done2 = false;
@@ -2385,6 +2436,8 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "wino")) g->opt_wino = value ? 1 : 0;
 #ifdef QGX_AB
     else if (!strcmp(name, "wino_exp")) g->opt_wino_exp = value;
+    else if (!strcmp(name, "wino_pl")) g->opt_wino_pl = value;
+    else if (!strcmp(name, "stop_layer")) g->opt_stop_layer = value;
 #endif
     else if (!strcmp(name, "wino_min_tiles")) { QGX_REQUIRE(value >= 1, "wino_min_tiles must be >= 1"); g->opt_wino_min_tiles = value; }
     else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
@@ -2405,6 +2458,14 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     return QGX_OK;
 }
 
+#ifdef QGX_AB
+// A/B library, debugging: copy the first nbytes of activation buffer `which` (0: the odd layers' outputs, 1: the even layers')
+extern "C" int qgx_debug_read_act(qgx_generator *g, int which, void *dst_dev, size_t nbytes, void *stream) {
+    QGX_REQUIRE(g && dst_dev, "qgx_debug_read_act: null argument");
+    QGX_HIP(hipMemcpyAsync(dst_dev, which ? (const void *)g->actB : (const void *)g->actA, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return QGX_OK;
+}
+#endif
 #ifdef QGX_STAMPS
 // diagnostic builds only (bench_tools/conv_stamps.py): where the s_memtime trace of k_convh_res goes
 extern "C" int qgx_debug_set_stamps(qgx_generator *g, void *buf, int layer) {

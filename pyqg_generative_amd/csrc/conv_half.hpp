@@ -148,6 +148,49 @@ __device__ __forceinline__ void store_tile_t(const f32x16 &acc, int cb, int h, c
     }
 }
 
+// Epilogue of one 32(pixels) x 32(out channels) accumulator tile in the UN-swapped layout (mfma(patch, weights)):
+// lane (li, h) owns output channel cb + li; register r holds pixel (r & 3) + 8 (r >> 2) + 4 h of the tile's 32
+// consecutive strip pixels.  Stores the channel-planar form the Winograd layer's MFMA input transform reads
+// (conv_wino.hpp): [b][y][c][hi | lo][x] f16 — after one v_permlane32_swap per register pair a lane holds 8 consecutive
+// pixels of its channel: lane half h stores the octets 2 m + h (m = 0, 1), 16 bytes of hi and 16 of lo each.
+// rowbase: the channel-0 hi row of the tile's first pixel's image row; p0: index of the tile's first pixel in the strip.
+__device__ __forceinline__ void store_tile_planar(const f32x16 &acc, int c, int h, char *strip, int p0, int N, int COUT,
+                                                  const float *bias, const float *scale, const float *shift, float unscale,
+                                                  float ascale, unsigned *range, unsigned range_bit, float guard_mul) {
+    const float bi = bias[c], sc = scale[c] * ascale, sh = shift[c] * ascale;     // ascale: a power of two, exact
+    float v[16];
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v[r] = fmaxf(acc[r] * unscale + bi, 0.f) * sc + sh;
+        mx = fmaxf(mx, fabsf(v[r]));
+    }
+    range_guard(mx * guard_mul, range, range_bit);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        // registers 8 m .. 8 m + 3: pixels 16 m + 4 h + (0..3) ("a"), 8 m + 4 .. 8 m + 7: pixels 16 m + 8 + 4 h + (0..3) ("b")
+        unsigned ah[2], bh[2], al[2], bl[2];
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const float a0 = v[8 * m + 2 * e2], a1 = v[8 * m + 2 * e2 + 1], b0 = v[8 * m + 4 + 2 * e2], b1 = v[8 * m + 5 + 2 * e2];
+            const _Float16 a0h = (_Float16)a0, a1h = (_Float16)a1, b0h = (_Float16)b0, b1h = (_Float16)b1;
+            ah[e2] = pack_h2((float)a0h, (float)a1h); bh[e2] = pack_h2((float)b0h, (float)b1h);
+            al[e2] = pack_h2(a0 - (float)a0h, a1 - (float)a1h); bl[e2] = pack_h2(b0 - (float)b0h, b1 - (float)b1h);
+        }
+        auto s0 = __builtin_amdgcn_permlane32_swap(ah[0], bh[0], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(ah[1], bh[1], false, false);
+        const u32x4 oh = {s0[0], s1[0], s0[1], s1[1]};
+        s0 = __builtin_amdgcn_permlane32_swap(al[0], bl[0], false, false);
+        s1 = __builtin_amdgcn_permlane32_swap(al[1], bl[1], false, false);
+        const u32x4 ol = {s0[0], s1[0], s0[1], s1[1]};
+        const int px = p0 + 8 * (2 * m + h);                  // first of this lane's 8 consecutive strip pixels
+        const int y = px / N, x = px - y * N;
+        char *o = strip + (((size_t)y * COUT + c) * 2 * N + x) * 2;
+        *reinterpret_cast<u32x4 *>(o) = oh;
+        *reinterpret_cast<u32x4 *>(o + 2 * N) = ol;
+    }
+}
+
 #ifdef QGX_AB   // generic run-time-N kernel (and the plain-f16 mode): A/B builds only, see conv.hip
 template <int CIN, int COUT, int KS, int NS, int MT, int TPS, int PPT, bool OUTF32, int NW = 8, bool SWZ = false>
 __global__ __launch_bounds__(NW * 64) void k_convh(ConvHArgs a, int total_tiles) {
@@ -781,7 +824,7 @@ struct ConvHFirstArgs {
     unsigned range_bit;
 };
 
-template <int NIN, int MT, int PPT, int NW = 4>
+template <int NIN, int MT, int PPT, int NW = 4, bool PLANAR = false>
 __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int total_tiles) {
     constexpr int NTHR = NW * 64;
     constexpr int KS = 5, P = 2, T = 25, COUT = 128;
@@ -873,6 +916,11 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
         const int mt = e >> 1, nt = e & 1;
         const int tile = wave + NW * mt;
         if (tile >= ntiles) return;
+        if constexpr (PLANAR) {
+            store_tile_planar(ac[mt][nt], half_of * 64 + nt * 32 + li, h, obase, tile * 32, N, COUT, ep, ep + COUT, ep + 2 * COUT,
+                              a.unscale, a.ascale, a.range, a.range_bit, a.guard_mul);
+            return;
+        }
         char *pix = obase + (size_t)(tile * 32 + li) * (COUT * 4);
         store_tile_t<2, false>(ac[mt][nt], half_of * 64 + nt * 32, h, pix, ep, ep + COUT, ep + 2 * COUT, a.unscale, a.ascale, a.range, a.range_bit, a.guard_mul);
     };
@@ -933,9 +981,15 @@ __global__ __launch_bounds__(NW * 64) void k_convh_first(ConvHFirstArgs a, int t
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], Ph[mt], acc[half][mt][nt], 0, 0, 0);
-                        acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Pl[mt], acc[half][mt][nt], 0, 0, 0);
-                        acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Ph[mt], acc[half][mt][nt], 0, 0, 0);
+                        if constexpr (PLANAR) {     // operands exchanged: the tile comes out transposed, lane = output channel
+                            acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph[mt], W[nt][1], acc[half][mt][nt], 0, 0, 0);
+                            acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Pl[mt], W[nt][0], acc[half][mt][nt], 0, 0, 0);
+                            acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph[mt], W[nt][0], acc[half][mt][nt], 0, 0, 0);
+                        } else {
+                            acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][1], Ph[mt], acc[half][mt][nt], 0, 0, 0);
+                            acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Pl[mt], acc[half][mt][nt], 0, 0, 0);
+                            acc[half][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W[nt][0], Ph[mt], acc[half][mt][nt], 0, 0, 0);
+                        }
                     }
                 if (have_prev) {
 #pragma unroll
