@@ -836,7 +836,8 @@ struct qgx_generator {
     int opt_stop_layer = 0;        //   A/B library, debugging: return after this many layers (the activation buffers keep their outputs)
     int opt_wino_pl = 0;           //   A/B library: 1 = channel-planar layer-1 output and the MFMA input transform (measured: see wino_planar)
     int opt_wino_exp = 0;          //   A/B library: timing experiments (conv_wino.hpp EXP)
-    int opt_wino_min_tiles = 128;  //   ... from this many 8-row tiles on (below it the persistent workgroups do not fill the CUs)
+    int opt_wino_min_tiles = 64;   //   ... from this many 512-pixel tiles on (measured crossovers, bench_tools/ab_conv.py: 64 tiles a tie or a
+                                   //   few % ahead of the 25-tap kernels on every grid, 96-144 tiles 12-28 % ahead)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
     int opt_part_max_tiles = 112;  // f16x3: split K on the wide layers below this many tiles (crossover: 7 members at 64x64)
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
