@@ -844,6 +844,7 @@ struct qgx_generator {
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
     int opt_half_min_tiles = 1;
     int opt_pair_lp = 1;           // A/B library only: 0 = the pair kernels fetch the two halves of a line in different chunk iterations
+    int opt_fuse96 = 2;            // ... at 96 x 96 (4-row strips): bit 0 (5,6), 1 (7,8)
     int opt_fuse = 3;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
     int opt_pair = 1;              // 3x3 k_convh2: fetch both 64-byte halves of a pixel's 128-byte line together
     int opt_h2 = 3;                // bit 1: k_convh2 for the 5x5 layer, bit 0: for the 3x3 layers (64x64 grids)
@@ -1746,11 +1747,11 @@ static int launch_convh4(qgx_generator *g, int layer, const LayerHost &L, const 
 // two fused 3x3 layers (k_convh_pair); 64 x 64 grids
 #endif  // QGX_AB
 
-template <int CINA, bool LAST, bool BOUTF32>
+template <int CINA, bool LAST, bool BOUTF32, int NN = 64, int R = 8>
 static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, const LayerHost &LB, const void *in,
                              void *out, int B, int N, int n_out, hipStream_t st) {
-    constexpr int NN = 64, R = 8, PW = NN + 2;
-    QGX_REQUIRE(N == NN, "generator: fused layer pairs need N=%d", NN);
+    constexpr int PW = NN + 2;
+    QGX_REQUIRE(N == NN, "generator: fused layer pairs compiled for N=%d", NN);
     constexpr size_t reg0 = (size_t)(R + 2) * PW * 144 > (size_t)(R + 4) * PW * 80 ? (size_t)(R + 2) * PW * 144 : (size_t)(R + 4) * PW * 80;
     constexpr size_t lds = reg0 + 3 * (9 * 4 * 32 * 16) + 2 * 96 * sizeof(float);
     static_assert(lds <= 160 * 1024, "LDS");
@@ -1767,9 +1768,9 @@ static int launch_convh_pair(qgx_generator *g, int layerA, const LayerHost &LA, 
     const int total_tiles = B * (N / R);
     int grid = 256;
     if (grid > total_tiles) grid = total_tiles;
-    auto kern = k_convh_pair<CINA, NN, LAST, BOUTF32>;
+    auto kern = k_convh_pair<CINA, NN, LAST, BOUTF32, CINA == 32, R>;
 #ifdef QGX_AB
-    if (!g->opt_pair_lp) kern = k_convh_pair<CINA, NN, LAST, BOUTF32, false>;
+    if (!g->opt_pair_lp) kern = k_convh_pair<CINA, NN, LAST, BOUTF32, false, R>;
 #endif
     { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, a, total_tiles);
@@ -2013,6 +2014,24 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         }
         if ((rc = conv3x3_half<64, 32, NS, false>(g, 2, net.L[2], Bb, A, Bc, N, st))) return rc;
         if ((rc = conv3x3_half<32, 32, NS, false>(g, 3, net.L[3], A, Bb, Bc, N, st))) return rc;
+        if (NS == 2 && g->opt_fuse96 && N == 96 && net.n_out <= 2 && Bc * 24 >= 256) {
+            // 96 x 96: the pair kernel on 4-row strips (a 6-row intermediate patch of 98 columns is 85 KB); "fuse96" bits as "fuse"
+            float *cur = Bb, *oth = A;
+            if (g->opt_fuse96 & 1) {
+                if ((rc = launch_convh_pair<32, false, false, 96, 4>(g, 4, net.L[4], net.L[5], cur, oth, Bc, N, 0, st))) return rc;
+                std::swap(cur, oth);
+            } else {
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], cur, oth, Bc, N, st))) return rc;
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 5, net.L[5], oth, cur, Bc, N, st))) return rc;
+            }
+            if (g->opt_fuse96 & 2) {
+                if ((rc = launch_convh_pair<32, true, false, 96, 4>(g, 6, net.L[6], net.L[7], cur, yc, Bc, N, net.n_out, st))) return rc;
+            } else {
+                if ((rc = conv3x3_half<32, 32, NS, true>(g, 6, net.L[6], cur, oth, Bc, N, st))) return rc;
+                if ((rc = launch_conv_last(g, net.L[7], oth, yc, Bc, N, net.n_out, st))) return rc;
+            }
+            continue;
+        }
         if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], Bb, A, Bc, N, st))) return rc;
         if ((rc = conv3x3_half<32, 32, NS, false>(g, 5, net.L[5], A, Bb, Bc, N, st))) return rc;
         if ((rc = conv3x3_half<32, 32, NS, true>(g, 6, net.L[6], Bb, A, Bc, N, st))) return rc;
@@ -2427,6 +2446,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "h2")) g->opt_h2 = value & 3;
     else if (!strcmp(name, "pair")) g->opt_pair = value ? 1 : 0;
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
+    else if (!strcmp(name, "fuse96")) g->opt_fuse96 = value & 3;
 #ifdef QGX_AB
     else if (!strcmp(name, "pair_lp")) g->opt_pair_lp = value;
 #endif

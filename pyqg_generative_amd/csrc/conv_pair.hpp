@@ -32,9 +32,9 @@ struct ConvPairArgs {
     unsigned long long *stamps;   // diagnostic builds (-DQGX_STAMPS) only
 };
 
-template <int CINA, int NN, bool LAST, bool BOUTF32, bool LP = (CINA == 32)>
+template <int CINA, int NN, bool LAST, bool BOUTF32, bool LP = (CINA == 32), int RR = 8>
 __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_tiles) {
-    constexpr int NW = 8, NTHR = 512, N = NN, R = 8, T = 9;
+    constexpr int NW = 8, NTHR = 512, N = NN, R = RR, T = 9;
     constexpr int NCA = CINA / 16;
     constexpr int PIXB = CINA * 4;
     constexpr int PW = NN + 2;
@@ -44,10 +44,11 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
     constexpr int WSLICE = T * 4 * 32 * 16;              // one 16-channel chunk of a 3x3 x 32 layer
     constexpr int WB_BYTES = 2 * WSLICE;
     constexpr int NTA = RA * NN / 32;                    // M-tiles of phase A (20 at 64 x 64)
-    constexpr int MTA = (NTA + NW - 1) / NW, MTB = R * NN / 32 / NW;
+    constexpr int NTB = R * NN / 32;                     // M-tiles of phase B (16 at 64 x 64; 12 at 96 x 96 with R = 4)
+    constexpr int MTA = (NTA + NW - 1) / NW, MTB = (NTB + NW - 1) / NW;
     constexpr int PU = RI * PW * 4, PPT = (PU + NTHR - 1) / NTHR;
     constexpr int WU = WSLICE / 16, WPT = (WU + NTHR - 1) / NTHR;
-    static_assert(R * NN / 32 % NW == 0 && NN % R == 0, "shape");
+    static_assert(R * NN % 32 == 0 && RA * NN % 32 == 0 && NN % R == 0, "shape");
     char *const reg0 = conv_smem;
     char *const wB = conv_smem + REG0;
     char *const wA = wB + WB_BYTES;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
     // per-lane base addresses (tap offsets are compile-time): phase A tile slot mt -> pixel of the RA x NN
     // block, phase B -> pixel of the R x NN block; both patches put pixel (r, x) at row r, column x
     int abase[MTA], bbase[MTB];
-    bool avalid[MTA];
+    bool avalid[MTA], bvalid[MTB];
 #pragma unroll
     for (int mt = 0; mt < MTA; ++mt) {
         const int tile = wave + NW * mt;
@@ -161,7 +162,9 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
     }
 #pragma unroll
     for (int mt = 0; mt < MTB; ++mt) {
-        const int p = (wave + NW * mt) * 32 + li;
+        const int tile = wave + NW * mt;
+        bvalid[mt] = tile < NTB;                         // wave-uniform
+        const int p = (bvalid[mt] ? tile : 0) * 32 + li;
         const int r = p / NN, x = p - r * NN;
         bbase[mt] = (r * PW + x) * MSTR + h * 32;
     }
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mt = 0; mt < MTB; ++mt) {
+                    if (!bvalid[mt]) continue;           // wave-uniform
                     accB[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[1], Pc[mt][0], accB[mt], 0, 0, 0);
                     accB[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[0], Pc[mt][1], accB[mt], 0, 0, 0);
                     accB[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[0], Pc[mt][0], accB[mt], 0, 0, 0);
@@ -346,6 +350,7 @@ __global__ __launch_bounds__(512) void k_convh_pair(ConvPairArgs a, int total_ti
             const int y0 = (tile_g - b * tiles_per_img) * R;
 #pragma unroll
             for (int mt = 0; mt < MTB; ++mt) {
+                if (!bvalid[mt]) continue;
                 const int p = (wave + NW * mt) * 32 + li;
                 if constexpr (LAST) {
                     // bare conv: channel c <= 1 is register c of the lanes with h = 0
