@@ -153,7 +153,8 @@ def layer2_kernel(gen, precision, N, B):
 
 def mfma_roofline(gen, precision, N, B, kname, traffic, stride=10, executed_per_flop=3.0):
     """roofline object of the dominant kernel (generator layer 2: 75 % of the FLOPs) from the HIP events the
-    library recorded around its launches inside the timed region"""
+    library recorded around its launches inside the timed region.  B = members PER LAUNCH (half of the resident
+    ensemble when qgx_step advances it as two halves on two streams, EnsembleEngine.step_streams)"""
     ms, n = gen.profile_read()
     gen.profile(-1)
     flop = 2.0 * MAC_PER_PIXEL[1] * N * N * B
@@ -162,6 +163,7 @@ def mfma_roofline(gen, precision, N, B, kname, traffic, stride=10, executed_per_
     peak = F32_MFMA_PEAK_TFLOPS if precision == 'f32' else F16_MFMA_PEAK_TFLOPS
     r = {'bound': 'mfma', 'kernel': kname, 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
          'frac': achieved / peak, 'traffic': traffic, 'flop_per_launch': flop, 'avg_launch_ms': avg_s * 1e3,
+         'members_per_launch': B,
          'launches_timed': n, 'launches_timed_note': f'HIP events bracket every {stride}th launch of the timed region',
          'peak_note': ('dense f32 MFMA peak; ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)' if precision == 'f32'
                        else 'dense f16 MFMA peak; `achieved` counts ALGORITHMIC flops (2 x 204,800 MAC/px x N^2 x B per launch)')}
@@ -226,21 +228,34 @@ def cpu_baseline(N, kind, dt, target_seconds=15.0):
                 one_core=r1, cores_share=share, share_rate=rm)
 
 
-def leg_config3(qa, device, K=200, W=10):
-    """BASELINE configs[3]'s per-GPU shard: 96x96 jet + CVAE decoder, 32 members; 200 timed steps."""
+def leg_config3(qa, device, K=200, W=10, one_stream=False):
+    """BASELINE configs[3]'s per-GPU shard: 96x96 jet + CVAE decoder, 32 members; 200 timed steps.
+    one_stream (--one-stream; the PMC passes behind profiles/): whole-ensemble launches only, so that per-launch counters
+    describe one kernel shape"""
     N, B = 96, 32
     dt = dt_of(N)
     gen, _ = load_generator('vae', device)
     eng = qa.EnsembleEngine(nx=N, n_members=B, device=device, dt=dt, **JET)
+    if one_stream:
+        eng.set_option('streams', 1)
     eng.set_q(eddy_like_q(np.arange(B), N))
     loop = OnlineLoop(eng, dt, dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024))
     loop.run(W)
-    gen.set_option('prof_every', prof_stride(K))
-    gen.profile(1)
     el = timed(lambda: loop.run(K))
+    # roofline of the layer-2 kernel: the timed region advances the ensemble as two halves on two streams (qgx_step_streams),
+    # where the wall time of one kernel contains the other stream's share of the GPU; the kernel is therefore timed in a
+    # separate pass of 40 steps on ONE stream (whole-ensemble launches, nothing beside them)
+    parts = eng.step_streams(gen)
+    eng.set_option('streams', 1)
+    gen.set_option('prof_every', 2)
+    gen.profile(1)
+    loop.run(40)
+    eng.set_option('streams', 1 if one_stream else 0)
     kn, ex = layer2_kernel(gen, 'f16x3', N, B)
     roof = mfma_roofline(gen, 'f16x3', N, B, kn + ' at 96x96 (generator layer 2)',
-                         pmc_traffic('pmc_traffic_config3.json', {'nx': N, 'members_per_gpu': B, 'kind': 'vae'}), prof_stride(K), ex)
+                         pmc_traffic('pmc_traffic_config3.json', {'nx': N, 'members_per_gpu': B, 'kind': 'vae'}), 2, ex)
+    roof['timed_in'] = ('a separate 40-step pass on one stream after the timed region' if parts > 1 else 'the timed region')
+    roof['streams_in_timed_region'] = parts
     ke, cfl = eng.status()
     out = {'workload': f'BASELINE configs[3] shard: jet {N}x{N} + CVAE, {B} members on 1 GPU (256 members / 8 GPUs), '
                        f"sampling='constant' nsteps=1, dt={dt:.0f}s",
@@ -331,8 +346,9 @@ def leg_members(qa, device, gen, B, K, W, name, note):
            'ms_per_step': 1e3 * el / K, 'snapshots_in_timed_region': loop.nsnap - n0[0],
            'status_checks_in_timed_region': loop.nstatus - n0[1]}
     if B >= 8:
-        kn, ex = layer2_kernel(gen, 'f16x3', N, B)
-        out['roofline'] = mfma_roofline(gen, 'f16x3', N, B, kn + ' (generator layer 2)', None, prof_stride(K), ex)
+        Bl = B // e.step_streams(gen)
+        kn, ex = layer2_kernel(gen, 'f16x3', N, Bl)
+        out['roofline'] = mfma_roofline(gen, 'f16x3', N, Bl, kn + ' (generator layer 2)', None, prof_stride(K), ex)
     else:
         gen.profile_read()
         gen.profile(-1)
@@ -357,6 +373,8 @@ def main():
                          'f32 = exact f32 MFMA')
     ap.add_argument('--no-aux', action='store_true', help='skip the steady / exact_f32 / b1 / b1024 / config3 / config4 legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--one-stream', action='store_true',
+                    help='config3 leg: never advance the ensemble as two halves on two streams (PMC passes of profiles/)')
     ap.add_argument('--leg', default='all', choices=['all', 'config3', 'config4', 'b1', 'b1024'],
                     help='profiling runs: only the named auxiliary leg (prints its JSON object)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -389,7 +407,7 @@ def main():
              'spectral step, k_step_small<64,false> at 512 threads)')
     if args.leg != 'all':
         if args.leg in ('config3', 'config4'):
-            res = {'config3': leg_config3, 'config4': leg_config4}[args.leg](qa, local_rank)
+            res = (leg_config3(qa, local_rank, one_stream=args.one_stream) if args.leg == 'config3' else leg_config4(qa, local_rank))
         else:
             g, _ = load_generator(args.kind, local_rank)
             res = leg_members(qa, local_rank, g, *{'b1': (1, 2000, 100, 'b1', B1), 'b1024': (1024, 250, 10, 'b1024', B1024)}[args.leg])
@@ -446,14 +464,15 @@ def main():
     healthy = bool(np.isfinite(ke).all() and (cfl < 1).all())
 
     out = None
-    kname, executed = layer2_kernel(gen, args.precision, N, B)
+    Bl = B // eng.step_streams(gen)              # members per launch (the ensemble advances as two halves on two streams)
+    kname, executed = layer2_kernel(gen, args.precision, N, Bl)
     kname += ' (generator layer 2)'
-    cfg = {'nx': N, 'members_per_gpu': B, 'kind': args.kind}
+    cfg = {'nx': N, 'members_per_gpu': B, 'members_per_launch': Bl, 'kind': args.kind}
     traffic = {'f32': pmc_traffic('pmc_traffic.json', cfg), 'f16x3': pmc_traffic('pmc_traffic_f16x3.json', cfg)}[args.precision]
     gen_flop_per_member_step = 2.0 * sum(MAC_PER_PIXEL) * N * N * (2 if args.kind == 'gz' else 1)
     if rank == 0:
         value = total_members * K / elapsed
-        roof = mfma_roofline(gen, args.precision, N, B, kname, traffic, stride, executed or 3.0)
+        roof = mfma_roofline(gen, args.precision, N, Bl, kname, traffic, stride, executed or 3.0)
         roof['whole_step_generator_tflops'] = gen_flop_per_member_step * value / world / 1e12
         dtype = {'f32': 'f64 spectral core + f32 generator (exact-f32 MFMA)',
                  'f16x3': 'f64 spectral core + generator in f16 hi/lo split operands, 3 f16 MFMAs per product, f32 accumulate '
@@ -491,7 +510,7 @@ def main():
         gen.profile(1)
         n0 = (loop.nsnap, loop.nstatus)
         els = timed(lambda: loop.run(KS))
-        rs = mfma_roofline(gen, args.precision, N, B, kname, traffic, 10, executed or 3.0)
+        rs = mfma_roofline(gen, args.precision, N, Bl, kname, traffic, 10, executed or 3.0)
         vs = B * KS / els
         rs['whole_step_generator_tflops'] = gen_flop_per_member_step * vs / 1e12
         out['steady'] = {'protocol': 'SURVEY 8(d): 100 warm-up + 2000 timed steps at the reference cadences, independent of --steps',
@@ -507,8 +526,8 @@ def main():
         gen.set_option('prof_every', 5)
         gen.profile(1)
         el32 = timed(lambda: loop.run(K32))
-        r32 = mfma_roofline(gen, 'f32', N, B, 'k_conv<128,64,5x5> (generator layer 2)',
-                            pmc_traffic('pmc_traffic.json', {'nx': N, 'members_per_gpu': B, 'kind': args.kind}), 5)
+        r32 = mfma_roofline(gen, 'f32', N, Bl, 'k_conv<128,64,5x5> (generator layer 2)',
+                            pmc_traffic('pmc_traffic.json', {'nx': N, 'members_per_gpu': B, 'members_per_launch': Bl, 'kind': args.kind}), 5)
         gen.set_option('precision', PRECISIONS[args.precision])
         out['exact_f32'] = {'value': B * K32 / el32, 'unit': 'ensemble-timesteps/sec', 'steps': K32,
                             'ms_per_step': 1e3 * el32 / K32, 'roofline': r32}
@@ -517,7 +536,7 @@ def main():
     if aux:
         out['b1'] = leg_members(qa, local_rank, gen, 1, 2000, 100, 'b1', B1)           # configs[1]
         out['b1024'] = leg_members(qa, local_rank, gen, 1024, 250, 10, 'b1024', B1024)  # configs[2] whole
-        out['config3'] = leg_config3(qa, local_rank)
+        out['config3'] = leg_config3(qa, local_rank, one_stream=args.one_stream)
         out['config4'] = leg_config4(qa, local_rank)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

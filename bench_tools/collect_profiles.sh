@@ -18,11 +18,12 @@ rocprofv3 --kernel-trace --pmc $M -d $OUT/pmcm_headline -- python bench.py $P > 
 echo headline pmc done
 # the legs run their own fixed protocols (config3: 10 + 200 steps; config4: 24 + 1000 steps, diagnostics cadence in the
 # second half, one coarse-grain)
+# (config3's PMC passes with --one-stream: whole-ensemble launches only, one kernel shape per name; its kernel stats as the leg runs)
 for leg in config3 config4; do
   rocprofv3 --kernel-trace --stats -d $OUT/stats_$leg -- python bench.py --leg $leg > $OUT/$leg.json 2> /dev/null
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcf_$leg -- python bench.py --leg $leg > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcw_$leg -- python bench.py --leg $leg > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmcf_$leg -- python bench.py --leg $leg --one-stream > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmcw_$leg -- python bench.py --leg $leg --one-stream > /dev/null 2>&1
   echo $leg done
 done
-rocprofv3 --kernel-trace --pmc $M -d $OUT/pmcm_config3 -- python bench.py --leg config3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $M -d $OUT/pmcm_config3 -- python bench.py --leg config3 --one-stream > /dev/null 2>&1
 ls $OUT

@@ -132,6 +132,12 @@ typedef struct qgx_param {
  * reported as QGX_ERR_HIP by the NEXT call that touches the model, whose state is then undefined.  Issue such calls
  * on one stream at a time. */
 int qgx_step(qgx_model *m, int nsteps_to_run, const qgx_param *p, int refresh_diag, void *stream);
+/* Small grids with a generator attached: an even ensemble may advance as two halves on two internal streams that fork from
+ * and join `stream` inside the call (members are independent — the reference runs them as separate processes,
+ * scripts/run_parameterized.py:55-63 — and the halves fill the idle phases of each other's launch chain); option "streams" of
+ * qgx_set_option: 0 automatic (96 x 96 with 16 ... 64 members, where it measured +9 ... +20 %), 1 never, 2 whenever even.  Returns the number of streams (1 or 2)
+ * qgx_step would use for this parameterization. */
+int qgx_step_streams(const qgx_model *m, const qgx_param *p);
 /* step counter / ablevel (m.tc) and reset of the AB history */
 int64_t qgx_step_count(const qgx_model *m);
 /* 256 x 256 grids: 1 after the census found the device fit for the single-launch runs of qgx_step, -1 if it did not

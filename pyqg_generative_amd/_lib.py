@@ -57,6 +57,7 @@ SYMBOLS = [
     ('qgx_field_bytes', C.c_size_t, [C.c_void_p, C.c_int]),
     ('qgx_invert', C.c_int, [C.c_void_p, C.c_void_p]),
     ('qgx_step', C.c_int, [C.c_void_p, C.c_int, C.POINTER(qgx_param), C.c_int, C.c_void_p]),
+    ('qgx_step_streams', C.c_int, [C.c_void_p, C.POINTER(qgx_param)]),
     ('qgx_step_count', C.c_int64, [C.c_void_p]),
     ('qgx_run_kernel_state', C.c_int, [C.c_void_p]),
     ('qgx_reset_time', C.c_int, [C.c_void_p]),

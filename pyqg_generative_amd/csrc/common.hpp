@@ -52,6 +52,7 @@ struct ModelOpts {
                                  //   (-1: while 6 B <= 256 | 0 | 1)
     int lsplit = -1;             // small grids: two workgroups per member, one per layer (-1 auto | 0 | 1)
     int spec_threads = 0;        // small grids: threads of the one-workgroup-per-member kernels (0 auto | 256 | 512 | 1024)
+    int streams = 0;             // small grids + generator: the two halves of the ensemble on two internal streams (0 auto: 96 x 96, 16..64 even members | 1 never | 2 whenever even)
     int team = 1;                // 256 x 256: XCD-resident runs of unparameterized steps
     int team_min = 2;            //   shortest run handed to that kernel
     int team_fault = 0;          //   A/B library only: raise the run kernel's flag at the end of the next run (test hook)
@@ -184,6 +185,9 @@ struct qgx_model {
     double *dg_S[7] = {};
     double *dg_acc[qgx::N_DIAGS] = {};
     double2 *dg_z = nullptr;               // large grids: the four work fields of the three-launch increment (spectral_large.hip)
+    // the two internal streams of a step in halves (model.hip::qgx_step) and their fork / join events
+    hipStream_t sub_stream[2] = {nullptr, nullptr};
+    hipEvent_t sub_event[3] = {nullptr, nullptr, nullptr};
 };
 
 namespace qgx {
@@ -211,6 +215,9 @@ int small_invert(const SpecDev &d, const ModelOpts &o, const double2 *qh, double
 
 bool generator_noise_is_double(const qgx_generator *g);
 int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st);
+int diag_ensure_alloc(qgx_model *m);      // the increment's work fields and accumulators (allocated at first use)
+// the generator's activation workspace for the calls that follow (1: the second half of an ensemble stepped in halves)
+int generator_select_workspace(qgx_generator *g, int idx);
 int noise_update(void *z, const void *xi_ext, bool is_double, int B, int n_per_member, uint64_t seed,
                  uint64_t member_offset, uint64_t step, double a, double b, hipStream_t st);
 int noise_normal(void *z, bool is_double, int B, int n_per_member, uint64_t seed,

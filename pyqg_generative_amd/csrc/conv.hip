@@ -818,6 +818,10 @@ struct qgx_generator {
     float *actA = nullptr, *actB = nullptr, *X = nullptr, *Y0 = nullptr, *Y1 = nullptr;
     float *part = nullptr;         // split-K partial sums of the small-ensemble path
     size_t part_elems = 0;
+    // second workspace: the other half of an ensemble stepped in halves on two streams (model.hip::qgx_step); the members
+    // above are the ACTIVE set, generator_select_workspace swaps the two
+    struct Workspace { size_t cap_elems = 0, part_elems = 0; float *actA = nullptr, *actB = nullptr, *X = nullptr, *Y0 = nullptr, *Y1 = nullptr, *part = nullptr; } ws_other;
+    int ws_active = 0;
     // optional per-layer timing with HIP events on the launch stream (bench.py roofline leg)
     // kernel variant selection (qgx_generator_set_option; defaults = fastest measured)
     int opt_cc = 32, opt_last_valu = 1, opt_first_split = 2, opt_v3 = -1, opt_small = 1;
@@ -2040,6 +2044,17 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
     return QGX_OK;
 }
 
+int generator_select_workspace(qgx_generator *g, int idx) {
+    QGX_REQUIRE(g && (idx == 0 || idx == 1), "generator_select_workspace: bad argument");
+    if (idx == g->ws_active) return QGX_OK;
+    std::swap(g->cap_elems, g->ws_other.cap_elems);
+    std::swap(g->actA, g->ws_other.actA); std::swap(g->actB, g->ws_other.actB);
+    std::swap(g->X, g->ws_other.X); std::swap(g->Y0, g->ws_other.Y0); std::swap(g->Y1, g->ws_other.Y1);
+    std::swap(g->part, g->ws_other.part); std::swap(g->part_elems, g->ws_other.part_elems);
+    g->ws_active = idx;
+    return QGX_OK;
+}
+
 static int reserve(qgx_generator *g, int B, int N) {
     const size_t need = (size_t)B * N * N;
     if (need <= g->cap_elems) return QGX_OK;
@@ -2383,7 +2398,8 @@ extern "C" int qgx_generator_destroy(qgx_generator *g) {
             if (L.wh16F) (void)hipFree(L.wh16F);
             for (float *p : {L.biasF, L.ones, L.zeros}) if (p) (void)hipFree(p);
         }
-    float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part};
+    float *bufs[] = {g->actA, g->actB, g->X, g->Y0, g->Y1, g->part,
+                     g->ws_other.actA, g->ws_other.actB, g->ws_other.X, g->ws_other.Y0, g->ws_other.Y1, g->ws_other.part};
     for (float *p : bufs) if (p) (void)hipFree(p);
     if (g->range_dev) (void)hipFree(g->range_dev);
     for (hipEvent_t e : g->prof_ev) (void)hipEventDestroy(e);

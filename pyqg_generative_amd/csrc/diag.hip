@@ -91,7 +91,7 @@ static int dalloc0(double *&p, size_t n) {
     return QGX_OK;
 }
 
-int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st) {
+int diag_ensure_alloc(qgx_model *m) {
     const SpecDev &d = m->d;
     const size_t nr = (size_t)d.B * 2 * d.N * d.N, ns2 = (size_t)d.B * 2 * d.N * d.NK * 2, n2d = (size_t)d.B * d.N * d.NK;
     int rc;
@@ -101,6 +101,14 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
         for (int i = 0; i < 2; ++i) if ((rc = dalloc0(m->dg_acc[i], ns2 / 2))) return rc;
         for (int i = 2; i < N_DIAGS; ++i) if ((rc = dalloc0(m->dg_acc[i], n2d))) return rc;
     }
+    return QGX_OK;
+}
+
+int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st) {
+    const SpecDev &d = m->d;
+    const size_t nr = (size_t)d.B * 2 * d.N * d.N;
+    int rc;
+    if ((rc = diag_ensure_alloc(m))) return rc;
     double2 *qh = m->qh[m->cur_q];
     double *p = m->dg_R[0], *xi = m->dg_R[1], *R3 = m->dg_R[2], *R4 = m->dg_R[3], *R5 = m->dg_R[4];
     double2 *xih = (double2 *)m->dg_S[0], *S3 = (double2 *)m->dg_S[1], *S4 = (double2 *)m->dg_S[2],

@@ -304,10 +304,13 @@ extern "C" int qgx_destroy(qgx_model *m) {
     (void)hipSetDevice(m->cfg.device);
     void *ptrs[] = {m->t_filtr, m->t_wv2, m->t_a, m->t_kk, m->t_ll, m->t_tw, m->t_pos, m->q, m->u, m->v,
                     m->S, m->qh[0], m->qh[1], m->ph, m->dqh, m->dq[0], m->dq[1], m->dq[2], m->dq[3], m->dg_z, m->zbuf, m->team_ctl,
-                    m->z, m->xi, m->dg_R[0], m->dg_R[1], m->dg_R[2], m->dg_R[3], m->dg_R[4], m->dg_S[0], m->dg_S[1],
-                    m->dg_S[2], m->dg_S[3], m->dg_S[4], m->dg_acc[0], m->dg_acc[1], m->dg_acc[2], m->dg_acc[3],
-                    m->dg_acc[4], m->dg_acc[5], m->dg_acc[6], m->dg_acc[7], m->dg_acc[8], m->dg_acc[9]};
+                    m->z, m->xi};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (double *p : m->dg_R) if (p) (void)hipFree(p);
+    for (double *p : m->dg_S) if (p) (void)hipFree(p);
+    for (double *p : m->dg_acc) if (p) (void)hipFree(p);
+    for (hipStream_t sst : m->sub_stream) if (sst) (void)hipStreamDestroy(sst);
+    for (hipEvent_t ev : m->sub_event) if (ev) (void)hipEventDestroy(ev);
     delete m;
     return QGX_OK;
 }
@@ -409,6 +412,7 @@ extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
     else if (!strcmp(name, "diag_fused")) o.diag_fused = value ? 1 : 0;
     else if (!strcmp(name, "diag_wide")) { QGX_REQUIRE(value >= -1 && value <= 1, "diag_wide must be -1 (auto), 0 or 1"); o.diag_wide = value; }
     else if (!strcmp(name, "lsplit")) { QGX_REQUIRE(value >= -1 && value <= 1, "lsplit must be -1 (auto), 0 or 1"); o.lsplit = value; }
+    else if (!strcmp(name, "streams")) { QGX_REQUIRE(value >= 0 && value <= 2, "streams must be 0 (auto), 1 or 2"); o.streams = value; }
     else if (!strcmp(name, "spec_threads")) {
         QGX_REQUIRE(value == 0 || value == 256 || value == 512 || value == 1024, "spec_threads must be 0 (auto), 256, 512 or 1024");
         o.spec_threads = value;
@@ -459,10 +463,8 @@ extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
 
 // ---- the stepping loop: pyqg model.py::_step_forward with the plugin call of
 // pyqg_generative/models/parameterization.py:23-34 and samplers of stochastic_pyqg.py:30-72
-extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refresh_diag, void *stream) {
-    QGX_NEEDS_STATE(m, "qgx_step");
-    QGX_REQUIRE(m && nsteps >= 0, "qgx_step: bad argument");
-    hipStream_t st = (hipStream_t)stream;
+// the steps of one call on one stream, for the whole ensemble or for one half of it (qgx_step below)
+static int step_core(qgx_model *m, int nsteps, const qgx_param *p, int refresh_diag, hipStream_t st) {
     const int N = m->N, B = m->B;
     if (p && p->gen) {
         QGX_REQUIRE(p->sampling == QGX_SAMPLING_AR1 || p->sampling == QGX_SAMPLING_CONSTANT,
@@ -473,7 +475,6 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         QGX_REQUIRE(!(p->z_external_dev && nsteps != 1), "qgx_step: external noise needs nsteps_to_run == 1");
         m->z_double = generator_noise_is_double(p->gen);
     }
-    { int trc = team_settle(m, st); if (trc) return trc; }
     const bool plain = !(p && (p->gen || p->forcing_dev));
     const bool fuse_ok = m->opts.genfuse != 0;
     m->x_ready_gen = nullptr;                                            // an assembled input never outlives its call
@@ -570,5 +571,95 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         int rc = model_step_once(m, has_S, S, weight, demean_in_kernel, diag, st, use_gf ? &gf : nullptr);
         if (rc) return rc;
     }
+    return QGX_OK;
+}
+
+// Two half-ensembles on two streams.  The online step is a chain of 7 dependent launches whose ramps, tails, kernel boundaries
+// and the step kernel's latency chain (one workgroup per member and layer) leave CUs idle; members are independent, so the two
+// halves of a shard can advance on two internal streams and fill each other's gaps.  A half is the SAME model over a slice:
+// every per-member array is member-major, so a child is a copy of the bookkeeping with B / 2 members and offset pointers; the
+// generator evaluates the halves in two workspaces.  Per-member results do not depend on it (Philox streams are keyed by the
+// global member id; the halves run the kernels the whole would whenever both sides of the few ensemble-size thresholds agree:
+// bit-identical at 64 x 64 / 128 and 96 x 96 / 32 members).
+// Measured with the bench's cadence (bench_tools/halves_cadence.py, one stream -> two): 96 x 96 with 16 / 32 / 48 / 64 / 128
+// members +20 / +11.5 / +20 / +9 / +2 %; 64 x 64 with 16 / 32 / 48 / 64 / 128 members -1 / 0 / +19 / 0 / +0.4 %; 48 x 48 with 32 /
+// 64 members -25 / +27 %; 32 x 32 with 64 members -5 %: on the smaller grids the sign follows the tile-count quantisation of the
+// halves against the whole, not a rule, so the automatic choice is the 96 x 96 grid (16 ... 64 members) only and option
+// "streams" = 2 asks for it elsewhere.
+static bool step_in_halves(const qgx_model *m, const qgx_param *p) {
+    if (m->opts.streams == 1 || !m->small || (m->B & 1) || !p || !p->gen || p->z_external_dev) return false;
+    if (m->opts.streams == 2) return true;
+    return m->N == 96 && m->B >= 16 && m->B <= 64;
+}
+
+extern "C" int qgx_step_streams(const qgx_model *m, const qgx_param *p) {
+    return m && !m->plan_only && step_in_halves(m, p) ? 2 : 1;
+}
+
+extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refresh_diag, void *stream) {
+    QGX_NEEDS_STATE(m, "qgx_step");
+    QGX_REQUIRE(m && nsteps >= 0, "qgx_step: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    { int trc = team_settle(m, st); if (trc) return trc; }
+    if (nsteps == 0 || !step_in_halves(m, p)) {
+        if (p && p->gen) { int wrc = generator_select_workspace(p->gen, 0); if (wrc) return wrc; }
+        return step_core(m, nsteps, p, refresh_diag, st);
+    }
+    const int N = m->N, NK = m->NK, Bp = m->B / 2;
+    for (int i = 0; i < 2; ++i) if (!m->sub_stream[i]) QGX_HIP(hipStreamCreateWithFlags(&m->sub_stream[i], hipStreamNonBlocking));
+    for (int i = 0; i < 3; ++i) if (!m->sub_event[i]) QGX_HIP(hipEventCreateWithFlags(&m->sub_event[i], hipEventDisableTiming));
+    if (m->dg_every > 0) { int arc = diag_ensure_alloc(m); if (arc) return arc; }   // BEFORE the children copy the pointers
+    // fork
+    QGX_HIP(hipEventRecord(m->sub_event[2], st));
+    qgx_model child[2] = {*m, *m};
+    qgx_param pp[2] = {*p, *p};
+    const size_t sr = (size_t)2 * N * N, ss = (size_t)2 * N * NK, s2 = (size_t)N * NK;
+    const size_t zbytes = generator_noise_is_double(p->gen) ? sizeof(double) : sizeof(float);
+    for (int c = 0; c < 2; ++c) {
+        QGX_HIP(hipStreamWaitEvent(m->sub_stream[c], m->sub_event[2], 0));
+        qgx_model &k = child[c];
+        const size_t b0 = (size_t)c * Bp;
+        k.B = Bp; k.d.B = Bp;
+        k.q += b0 * sr; k.u += b0 * sr; k.v += b0 * sr; k.S += b0 * sr;
+        k.qh[0] += b0 * ss; k.qh[1] += b0 * ss; k.ph += b0 * ss; k.dqh += b0 * ss;
+        for (int i = 0; i < 3; ++i) k.dq[i] += b0 * ss;
+        // latent noise and its scratch: dense (B, 2, N, N) of the element type in use (qgx_get(QGX_F_Z) reads it that way)
+        k.z = (char *)k.z + b0 * sr * zbytes;
+        k.xi = (char *)k.xi + b0 * sr * zbytes;
+        if (k.dg_R[0]) {
+            for (double *&r : k.dg_R) r += b0 * sr;
+            for (double *&r : k.dg_S) r += b0 * ss * 2;
+            for (int i = 0; i < qgx::N_DIAGS; ++i) k.dg_acc[i] += b0 * (i < 2 ? 2 * s2 : s2);
+        }
+        k.sub_stream[0] = k.sub_stream[1] = nullptr;
+        pp[c].member_offset = p->member_offset + b0;
+    }
+    // the halves take turns in chunks of steps (a chunk keeps the fused input / output kernels of consecutive steps fused and
+    // both streams fed: the host enqueues a chunk in a fraction of the time the GPU needs for it)
+    constexpr int CHUNK = 8;
+    int rc = QGX_OK;
+    for (int s0 = 0; s0 < nsteps && !rc; s0 += CHUNK) {
+        const int n = nsteps - s0 < CHUNK ? nsteps - s0 : CHUNK;
+        const int refresh = refresh_diag && s0 + n == nsteps;
+        for (int c = 0; c < 2 && !rc; ++c) {
+            if ((rc = generator_select_workspace(p->gen, c))) break;
+            rc = step_core(&child[c], n, &pp[c], refresh, m->sub_stream[c]);
+        }
+    }
+    (void)generator_select_workspace(p->gen, 0);
+    // join
+    for (int c = 0; c < 2; ++c) {
+        QGX_HIP(hipEventRecord(m->sub_event[c], m->sub_stream[c]));
+        QGX_HIP(hipStreamWaitEvent(st, m->sub_event[c], 0));
+    }
+    if (rc) return rc;
+    // the halves advanced in lockstep: the bookkeeping of either is the ensemble's
+    const qgx_model &k = child[0];
+    QGX_REQUIRE(k.tc == child[1].tc && k.cur_q == child[1].cur_q && k.i_new == child[1].i_new && k.noise_step == child[1].noise_step &&
+                k.dg_count == child[1].dg_count, "qgx_step: the two halves of the ensemble left the lockstep");
+    m->tc = k.tc; m->ablevel = k.ablevel; m->cur_q = k.cur_q; m->i_new = k.i_new; m->i_p = k.i_p; m->i_pp = k.i_pp; m->i_x = k.i_x;
+    m->z_double = k.z_double; m->have_noise = k.have_noise; m->const_counter = k.const_counter; m->have_forcing = k.have_forcing;
+    m->noise_step = k.noise_step; m->uv_stale = k.uv_stale; m->q_stale = k.q_stale; m->dg_count = k.dg_count;
+    m->x_ready_gen = nullptr;
     return QGX_OK;
 }

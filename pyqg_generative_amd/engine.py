@@ -335,6 +335,14 @@ class EnsembleEngine:
         if keep:
             torch.cuda.current_stream().synchronize()
 
+    def step_streams(self, generator=None):
+        """1 or 2: the internal streams `step` advances this ensemble on with `generator` attached (qgx_step_streams)"""
+        if generator is None:
+            return 1
+        p = _lib.qgx_param()
+        p.gen = generator._h
+        return int(lib.qgx_step_streams(self._h, C.byref(p)))
+
     def close(self):
         if self._h:
             lib.qgx_destroy(self._h)

@@ -280,3 +280,44 @@ def test_parameterized_diagnostics_with_many_members():
             # the forcing enters in float32 arithmetic on both sides (different summation order): 5e-5 of its maximum
             tol = 2e-4 if ('param' in name or 'Diss' in name) else 1e-6      # Dissspec: the forcing is part of the tendency
             assert np.abs(got[b] - ref).max() <= tol * np.abs(ref).max(), (name, b)
+
+
+def test_an_ensemble_stepped_as_two_halves_on_two_streams_is_the_same_ensemble():
+    """qgx_step advances a 96 x 96 ensemble of 16 ... 64 members as two halves on two internal streams (option `streams`:
+    0 automatic, 1 never, 2 whenever even; qgx_step_streams): a half is the same model over a slice of the member-major arrays,
+    the noise streams are keyed by the global member id, the diagnostics accumulators are per member — state, forcing and
+    time-averaged diagnostics are BIT-identical to the one-stream step where the halves run the kernels the whole runs
+    (96 x 96 / 32 members, 64 x 64 / 128), and equal to the float32 generator's rounding where an ensemble-size threshold separates them (48 x 48 / 20: split-K kernels
+    for the halves — which also checks that the two halves' split-K buffers are separate)."""
+    import pyqg_generative_amd as qa
+    from pyqg_generative_amd import _lib as L, weights
+    for N, B, kind, exact in ((96, 32, 'vae', True), (64, 128, 'gan', True), (48, 20, 'gan', False)):
+        nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind)
+        gen = qa.Generator(kind, nets, xs, ys)
+        rs = np.random.RandomState(N + B)
+        q0 = rs.randn(B, 2, N, N) * 1e-6
+        res = {}
+        for streams in (1, 2):
+            e = qa.EnsembleEngine(nx=N, n_members=B, dt=3600.)
+            e.set_option('streams', streams)
+            assert e.step_streams(gen) == streams
+            e.set_q(q0)
+            e.diag_config(2, 5)
+            kw = dict(generator=gen, sampling='AR1', nsteps_decor=3, seed=11, member_offset=7)
+            e.step(9, **kw)
+            e.step(14, refresh_diag=False, **kw)            # a second call continues both halves' samplers and AB3 histories
+            res[streams] = [e.get(f).cpu().numpy() for f in (L.F_QH, L.F_S, L.F_Z, L.F_U, L.F_DQHDT_PP)] + \
+                           [e.diag(n).cpu().numpy() for n in ('KEspec', 'paramspec', 'ENSparamspec', 'Dissspec')] + [e.tc, e.diag_count]
+            e.close()
+        assert res[1][-2:] == res[2][-2:] and res[1][-2] == 23 and res[1][-1] == 4
+        for a, b in zip(res[1][:-2], res[2][:-2]):
+            scale = np.abs(a).max()
+            if exact:
+                assert np.array_equal(a, b)
+            else:
+                assert np.abs(a - b).max() <= 2e-5 * scale      # float32 generator, other kernels at half the ensemble size
+        # the automatic choice: the 96 x 96 grid with 16 ... 64 members
+        e = qa.EnsembleEngine(nx=N, n_members=B, dt=3600.)
+        assert e.step_streams(gen) == (2 if N == 96 else 1) and e.step_streams(None) == 1
+        e.close()
+        gen.close()
