@@ -13,6 +13,8 @@ for N, B, kind in CASES:
     eng = qa.EnsembleEngine(nx=N, n_members=B, device=0, dt=dt)
     eng.set_q(bench.eddy_like_q(np.arange(B), N))
     loop = bench.OnlineLoop(eng, dt, dict(generator=gen, sampling='constant', nsteps_decor=1, seed=2024, member_offset=0))
+    if os.environ.get('QGX_HC_NODIAG'):          # developer switch of this tool: no time-averaged diagnostics in the loop
+        eng.diag_config(0, 0)
     loop.run(100)
     for rnd in range(2):
         for streams in (1, 2):
