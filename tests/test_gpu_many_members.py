@@ -291,7 +291,7 @@ def test_an_ensemble_stepped_as_two_halves_on_two_streams_is_the_same_ensemble()
     for the halves — which also checks that the two halves' split-K buffers are separate)."""
     import pyqg_generative_amd as qa
     from pyqg_generative_amd import _lib as L, weights
-    for N, B, kind, exact in ((96, 32, 'vae', True), (64, 128, 'gan', True), (48, 20, 'gan', False)):
+    for N, B, kind, exact in ((96, 32, 'vae', True), (64, 128, 'gan', True), (48, 20, 'gan', False), (64, 14, 'gz', False), (32, 6, 'vae', False)):
         nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind)
         gen = qa.Generator(kind, nets, xs, ys)
         rs = np.random.RandomState(N + B)
@@ -306,7 +306,9 @@ def test_an_ensemble_stepped_as_two_halves_on_two_streams_is_the_same_ensemble()
             kw = dict(generator=gen, sampling='AR1', nsteps_decor=3, seed=11, member_offset=7)
             e.step(9, **kw)
             e.step(14, refresh_diag=False, **kw)            # a second call continues both halves' samplers and AB3 histories
-            res[streams] = [e.get(f).cpu().numpy() for f in (L.F_QH, L.F_S, L.F_Z, L.F_U, L.F_DQHDT_PP)] + \
+            import torch
+            zt = torch.float64 if kind == 'gz' else torch.float32       # the mean / variance model draws float64 noise
+            res[streams] = [e.get(f, noise_dtype=zt).cpu().numpy() for f in (L.F_QH, L.F_S, L.F_Z, L.F_U, L.F_DQHDT_PP)] + \
                            [e.diag(n).cpu().numpy() for n in ('KEspec', 'paramspec', 'ENSparamspec', 'Dissspec')] + [e.tc, e.diag_count]
             e.close()
         assert res[1][-2:] == res[2][-2:] and res[1][-2] == 23 and res[1][-1] == 4
