@@ -840,6 +840,8 @@ struct qgx_generator {
     int opt_stop_layer = 0;        //   A/B library, debugging: return after this many layers (the activation buffers keep their outputs)
     int opt_wino_pl = 0;           //   A/B library: 1 = channel-planar layer-1 output and the MFMA input transform (measured: see wino_planar)
     int opt_wino_exp = 0;          //   A/B library: timing experiments (conv_wino.hpp EXP)
+    int opt_h2_rows96 = 0;         // 3x3 layers at 96 x 96: tile rows, 0 = by tile-count quantisation, 12 (6 waves), 16 (8 waves)
+    int opt_wino_rows96 = 0;       //   ... its tile rows at 96 x 96: 0 = by tile-count quantisation (launch_convw), 12, 16
     int opt_wino_min_tiles = 64;   //   ... from this many 512-pixel tiles on (measured crossovers, bench_tools/ab_conv.py: 64 tiles a tie or a
                                    //   few % ahead of the 25-tap kernels on every grid, 96-144 tiles 12-28 % ahead)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
@@ -1573,9 +1575,9 @@ static int launch_convh2_w8(qgx_generator *g, int layer, const LayerHost &L, con
 }
 
 // the 3x3 layers in the same 8-wave shape (64 x 64)
-template <int CIN, bool OUTF32, int NN = 64, int TW = NN>
+template <int CIN, bool OUTF32, int NN = 64, int TW = NN, int NW = 8>
 static int launch_convh2_w8_3x3(qgx_generator *g, int layer, const LayerHost &L, const void *in, void *out, int B, hipStream_t st) {
-    constexpr int COUT = 32, KS = 3, MT = 2, TPS = 9, NW = 8;
+    constexpr int COUT = 32, KS = 3, MT = 2, TPS = 9;
     constexpr int R = NW * MT * 32 / TW, PR = R + KS - 1, PW = TW + 2;
     constexpr size_t lds = (size_t)PR * PW * 80 + (size_t)2 * TPS * 4 * COUT * 16 + 3 * COUT * sizeof(float);
     hipEvent_t prof_stop;
@@ -1604,8 +1606,15 @@ static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const 
     if constexpr (KS == 3 && COUT == 32) {
         if ((g->opt_h2_w8 & 2) && g->opt_pair && N == 64 && B * 8 >= 256) return launch_convh2_w8_3x3<CIN, OUTF32>(g, layer, L, in, out, B, st);
         // 96 = 3 x 32: tiles of 16 rows x 32 columns give the 3x3 layers the two-M-tiles-per-wave 8-wave shape too
-        if ((g->opt_h2_w8 & 2) && g->opt_pair && g->opt_h2_x96 && N == 96 && B * 18 >= 256)
-            return launch_convh2_w8_3x3<CIN, OUTF32, 96, 32>(g, layer, L, in, out, B, st);
+        if ((g->opt_h2_w8 & 2) && g->opt_pair && g->opt_h2_x96 && N == 96 && B * 18 >= 256) {
+            // 16 x 32 tiles on 8 waves (18 per member) or 12 x 32 tiles on 6 waves (24 per member): by rounds x cost per tile, as the
+            // Winograd layer's shapes (launch_convw); a 6-wave tile costs 0.85 of an 8-wave one (measured: 32 members 32.4 -> 30.4 us
+            // per 32 -> 32 layer, 16 members 23.0 -> 21.1, 64 members 52.1 / 52.2)
+            const int r16 = (B * 18 + 255) / 256, r12 = (B * 24 + 255) / 256;
+            const bool rows12 = g->opt_h2_rows96 == 12 || (g->opt_h2_rows96 == 0 && 0.85 * r12 < 1.0 * r16);
+            return rows12 ? launch_convh2_w8_3x3<CIN, OUTF32, 96, 32, 6>(g, layer, L, in, out, B, st)
+                          : launch_convh2_w8_3x3<CIN, OUTF32, 96, 32>(g, layer, L, in, out, B, st);
+        }
     }
     if constexpr (KS == 5 && CIN == 128) {
         // one 8-wave workgroup per CU once its double-height tiles fill the CUs: -5.5 % at 64 x 64, -3.5 % at
@@ -1915,7 +1924,17 @@ static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int whi
         case 32: rc = launch_convw_n<32, 32, 16>(g, layer, L, which, in, out, B, st); break;
         case 48: rc = launch_convw_n<48, 16, 16>(g, layer, L, which, in, out, B, st); break;
         case 64: rc = launch_convw_n<64, 64, 8>(g, layer, L, which, in, out, B, st); break;
-        case 96: rc = launch_convw_n<96, 32, 16>(g, layer, L, which, in, out, B, st); break;
+        case 96: {
+            // 16 x 32 tiles (18 per member) or 12 x 32 (24 per member, 0.75 x the work each at a 1.33 x instead of 1.25 x row halo):
+            // 256 persistent workgroups take ceil(tiles / 256) rounds, so the shape is chosen by rounds x cost per tile — at 32 members
+            // 3 x 1.0 against 3 x 0.79 (measured 215 -> 171 us), at 24 members 2 x 1.0 against 3 x 0.79 (149 / 160 us), at 128 9 x 1.0
+            // against 12 x 0.79 (690 / 749 us)
+            const int r16 = (B * 18 + 255) / 256, r12 = (B * 24 + 255) / 256;
+            const bool rows12 = g->opt_wino_rows96 == 12 || (g->opt_wino_rows96 == 0 && 0.79 * r12 < 1.0 * r16);
+            rc = rows12 ? launch_convw_n<96, 32, 12>(g, layer, L, which, in, out, B, st)
+                        : launch_convw_n<96, 32, 16>(g, layer, L, which, in, out, B, st);
+            break;
+        }
         default: rc = launch_convw_n<128, 64, 8>(g, layer, L, which, in, out, B, st); break;
     }
     if (!rc) done = true;
@@ -2476,6 +2495,8 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "wino_pl")) g->opt_wino_pl = value;
     else if (!strcmp(name, "stop_layer")) g->opt_stop_layer = value;
 #endif
+    else if (!strcmp(name, "h2_rows96")) { QGX_REQUIRE(value == 0 || value == 12 || value == 16, "h2_rows96 must be 0 (auto), 12 or 16"); g->opt_h2_rows96 = value; }
+    else if (!strcmp(name, "wino_rows96")) { QGX_REQUIRE(value == 0 || value == 12 || value == 16, "wino_rows96 must be 0 (auto), 12 or 16"); g->opt_wino_rows96 = value; }
     else if (!strcmp(name, "wino_min_tiles")) { QGX_REQUIRE(value >= 1, "wino_min_tiles must be >= 1"); g->opt_wino_min_tiles = value; }
     else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
     else if (!strcmp(name, "h4")) g->opt_h4 = value;
