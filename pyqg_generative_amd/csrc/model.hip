@@ -581,8 +581,8 @@ static int step_core(qgx_model *m, int nsteps, const qgx_param *p, int refresh_d
 // generator evaluates the halves in two workspaces.  Per-member results do not depend on it (Philox streams are keyed by the
 // global member id; the halves run the kernels the whole would whenever both sides of the few ensemble-size thresholds agree:
 // bit-identical at 64 x 64 / 128 and 96 x 96 / 32 members).
-// Measured with the bench's cadence (bench_tools/halves_cadence.py, one stream -> two): 96 x 96 with 16 / 32 / 48 / 64 / 128
-// members +20 / +11.5 / +20 / +9 / +2 %; 64 x 64 with 16 / 32 / 48 / 64 / 128 members -1 / 0 / +19 / 0 / +0.4 %; 48 x 48 with 32 /
+// Measured with the bench's cadence (bench_tools/halves_cadence.py, one stream -> two): 96 x 96 with 16 / 24 / 32 / 48 / 64
+// members +6.5 / +4 / +4 / +11 / +1 % (before the 96 x 96 tile shapes were chosen by quantisation: +20 / . / +11.5 / +20 / +9 %); 64 x 64 with 16 / 32 / 48 / 64 / 128 members -1 / 0 / +19 / 0 / +0.4 %; 48 x 48 with 32 /
 // 64 members -25 / +27 %; 32 x 32 with 64 members -5 %: on the smaller grids the sign follows the tile-count quantisation of the
 // halves against the whole, not a rule, so the automatic choice is the 96 x 96 grid (16 ... 64 members) only and option
 // "streams" = 2 asks for it elsewhere.
