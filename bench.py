@@ -295,8 +295,14 @@ def leg_config4(qa, device, K=1000, W=24):
     every = int(math.ceil(86400. / dt))
     eng = qa.EnsembleEngine(nx=N, n_members=B, device=device, dt=dt)
     eng.set_q(eddy_like_q(np.arange(B), N))
+    # warm-up: W steps, one of them with a diagnostics increment so that the increment's work fields and accumulators (1.7 GB at
+    # this size, allocated and zeroed at first use) exist before the timed region, as they do in every snapshot interval of a
+    # run but its first; the accumulators are reset afterwards
+    eng.diag_config(1, 1)
+    eng.step(2)
+    eng.diag_reset()
     eng.diag_config(W + K // 2, every)              # tavestart in the middle of the timed interval
-    eng.step(W)
+    eng.step(W - 2)
     pp = dict(qa.engine.PYQG_DEFAULTS)
 
     def coarsegrain():                              # as generate_subgrid_forcing does at a snapshot
