@@ -850,6 +850,7 @@ struct qgx_generator {
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
     int opt_half_min_tiles = 1;
     int opt_pair_lp = 1;           // A/B library only: 0 = the pair kernels fetch the two halves of a line in different chunk iterations
+    int opt_small_tiles = 1;       // 64 x 64, at most 4 members: half-height tiles (small_tiles())
     int opt_fuse96 = 2;            // ... at 96 x 96 (4-row strips): bit 0 (5,6), 1 (7,8)
     int opt_fuse = 3;              // f16x3, 64x64: 3x3 layers fused pairwise (k_convh_pair): bit 0 (5,6), 1 (7,8), 2 (3,4)
     int opt_pair = 1;              // 3x3 k_convh2: fetch both 64-byte halves of a pixel's 128-byte line together
@@ -1155,6 +1156,11 @@ static int pack_layer(LayerHost &L, int li, const qgx_cnn_weights *w, bool plana
     if ((rc = upf(L.bias, bias)) || (rc = upf(L.scale, sc)) || (rc = upf(L.shift, sh))) return rc;
     return QGX_OK;
 }
+
+// Very small ensembles at 64 x 64 (a single member above all: BASELINE configs[1]) are chains of launch latencies; with 4-row
+// tiles a member is 16 workgroups, with 2-row tiles 32 with half the K loop each (bit-identical: the tile shape does not enter
+// the summation order).  Measured at one member: the 5x5 layer's split-K kernel + combine 23.6 -> 19.9 us, layer 3 12.1 -> 10.9.
+static bool small_tiles(const qgx_generator *g, int B, int N) { return g->opt_small_tiles && N == 64 && B * 16 <= 64; }
 
 static int choose_rows(int N) {
     if (N <= 256 && 256 % N == 0) return 256 / N;     // 8 M-tiles
@@ -1540,7 +1546,10 @@ static int launch_convh2_part(qgx_generator *g, int layer, const LayerHost &L, c
     switch (N) {
         case 32: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 32, 2>(g, layer, L, in, out, B, st);
         case 48: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 48, 3>(g, layer, L, in, out, B, st);
-        case 64: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 64, 2>(g, layer, L, in, out, B, st);
+        // (half-height tiles for the smallest ensembles: 32 instead of 16 workgroups per member and split — small_tiles())
+        case 64: return small_tiles(g, B, 64) && B == 1      // (at 4 members the 5x5 layer's 8 splits x 128 tiles are slower)
+                            ? launch_convh2_part_n<CIN, COUT, KS, OUTF32, 64, 1>(g, layer, L, in, out, B, st)
+                                              : launch_convh2_part_n<CIN, COUT, KS, OUTF32, 64, 2>(g, layer, L, in, out, B, st);
         case 96: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 96, 3>(g, layer, L, in, out, B, st);
         case 128: return launch_convh2_part_n<CIN, COUT, KS, OUTF32, 128, 2>(g, layer, L, in, out, B, st);
         default: done = false; return QGX_OK;
@@ -1630,7 +1639,8 @@ static int launch_convh2(qgx_generator *g, int layer, const LayerHost &L, const 
     switch (N) {
         case 32: return launch_convh2_n<CIN, COUT, KS, OUTF32, 32, 2>(g, layer, L, in, out, B, st);
         case 48: return launch_convh2_n<CIN, COUT, KS, OUTF32, 48, 3>(g, layer, L, in, out, B, st);
-        case 64: return launch_convh2_n<CIN, COUT, KS, OUTF32, 64, 2>(g, layer, L, in, out, B, st);
+        case 64: return small_tiles(g, B, 64) ? launch_convh2_n<CIN, COUT, KS, OUTF32, 64, 1>(g, layer, L, in, out, B, st)
+                                              : launch_convh2_n<CIN, COUT, KS, OUTF32, 64, 2>(g, layer, L, in, out, B, st);
         case 96: return launch_convh2_n<CIN, COUT, KS, OUTF32, 96, 3>(g, layer, L, in, out, B, st);
         case 128: return launch_convh2_n<CIN, COUT, KS, OUTF32, 128, 2>(g, layer, L, in, out, B, st);
         default: done = false; return QGX_OK;
@@ -1802,12 +1812,14 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
     // the younger finishes 30 % later (global-clock stamps), and the 57 KB weight set is staged once per CU
     const bool w8 = g->opt_h2_w8 && R * N / 32 == 8 && N % (2 * R) == 0 && B * (N / (2 * R)) >= 256;
     if (w8) R *= 2;
+    const bool half_rows = !w8 && small_tiles(g, B, N) && R % 2 == 0;      // one M-tile per wave (small_tiles())
+    if (half_rows) R /= 2;
     const int nw = w8 ? 8 : 4;
     const int PR = R + 4, ntiles = R * N / 32;
     constexpr int nstep = NIN == 4 ? 7 : 4;
     const size_t lds = (size_t)nstep * 4 * 128 * 16 + (size_t)2 * PR * N * NIN * 4 + 3 * 128 * sizeof(float);
     const int ppt = (PR * NIN * (N / 4) + nw * 64 - 1) / (nw * 64);
-    QGX_REQUIRE(lds <= 160 * 1024 - 256 && ppt <= 3 && (ntiles == 2 * nw || ntiles == 3 * nw),
+    QGX_REQUIRE(lds <= 160 * 1024 - 256 && ppt <= 3 && (ntiles == 2 * nw || ntiles == 3 * nw || (half_rows && ntiles == nw)),
                 "generator: 16-bit first layer unsupported for N=%d", N);
     hipEvent_t prof_stop;
     { int prc = prof_begin(g, 0, st, prof_stop); if (prc) return prc; }
@@ -1832,7 +1844,8 @@ static int launch_convh_first(qgx_generator *g, const LayerHost &L, const float 
         { const int lrc_ = ensure_dynamic_lds((const void *)kern, (int)lds); if (lrc_) return lrc_; } \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, a, total_tiles);                        \
     }
-    if (w8) { if (ppt <= 2) QGX_LF(2, 2, 8) else QGX_LF(2, 3, 8) }
+    if (half_rows) { if (ppt <= 2) QGX_LF(1, 2, 4) else QGX_LF(1, 3, 4) }
+    else if (w8) { if (ppt <= 2) QGX_LF(2, 2, 8) else QGX_LF(2, 3, 8) }
     else if (ntiles == 8) { if (ppt <= 2) QGX_LF(2, 2, 4) else QGX_LF(2, 3, 4) }
     else { if (ppt <= 2) QGX_LF(3, 2, 4) else QGX_LF(3, 3, 4) }
 #undef QGX_LF
@@ -2482,6 +2495,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "pair")) g->opt_pair = value ? 1 : 0;
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
     else if (!strcmp(name, "fuse96")) g->opt_fuse96 = value & 3;
+    else if (!strcmp(name, "small_tiles")) g->opt_small_tiles = value ? 1 : 0;
 #ifdef QGX_AB
     else if (!strcmp(name, "pair_lp")) g->opt_pair_lp = value;
 #endif
