@@ -841,6 +841,7 @@ struct qgx_generator {
     int opt_wino_pl = 0;           //   A/B library: 1 = channel-planar layer-1 output and the MFMA input transform (measured: see wino_planar)
     int opt_wino_exp = 0;          //   A/B library: timing experiments (conv_wino.hpp EXP)
     int opt_h2_rows96 = 0;         // 3x3 layers at 96 x 96: tile rows, 0 = by tile-count quantisation, 12 (6 waves), 16 (8 waves)
+    int opt_wino_rows64 = 0;       //   ... its tile rows at 64 x 64: 0 = by tile-count quantisation, 4, 8
     int opt_wino_rows96 = 0;       //   ... its tile rows at 96 x 96: 0 = by tile-count quantisation (launch_convw), 12, 16
     int opt_wino_min_tiles = 64;   //   ... from this many 512-pixel tiles on (measured crossovers, bench_tools/ab_conv.py: 64 tiles a tie or a
                                    //   few % ahead of the 25-tap kernels on every grid, 96-144 tiles 12-28 % ahead)
@@ -1936,7 +1937,16 @@ static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int whi
     switch (N) {
         case 32: rc = launch_convw_n<32, 32, 16>(g, layer, L, which, in, out, B, st); break;
         case 48: rc = launch_convw_n<48, 16, 16>(g, layer, L, which, in, out, B, st); break;
-        case 64: rc = launch_convw_n<64, 64, 8>(g, layer, L, which, in, out, B, st); break;
+        case 64: {
+            // 8-row tiles (8 per member) or 4-row tiles (16 per member, half the work each at a 2 x instead of 1.5 x row halo): by
+            // rounds x cost per tile as at 96 x 96 — the small shape pays while the large one leaves CUs idle (measured, layer time in
+            // us, 8 / 4 rows: 8 members 65 / 44, 16: 69 / 50, 24: 74 / 87, 31: 80 / 92, 48: 139 / 134 -> 0.66 per tile)
+            const int r8 = (B * 8 + 255) / 256, r4 = (B * 16 + 255) / 256;
+            const bool rows4 = g->opt_wino_rows64 == 4 || (g->opt_wino_rows64 == 0 && 0.66 * r4 < 1.0 * r8);
+            rc = rows4 ? launch_convw_n<64, 64, 4>(g, layer, L, which, in, out, B, st)
+                       : launch_convw_n<64, 64, 8>(g, layer, L, which, in, out, B, st);
+            break;
+        }
         case 96: {
             // 16 x 32 tiles (18 per member) or 12 x 32 (24 per member, 0.75 x the work each at a 1.33 x instead of 1.25 x row halo):
             // 256 persistent workgroups take ceil(tiles / 256) rounds, so the shape is chosen by rounds x cost per tile — at 32 members
@@ -2033,6 +2043,8 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
             }
             // here the activation is in A (fused pair) or Bb (two kernels)
             float *cur = (g->opt_fuse & 4) ? A : Bb, *oth = (g->opt_fuse & 4) ? Bb : A;
+            // (4-row strips for the pairs, as the Winograd layer's small shape, measured slower at 8 ... 48 members: 25.4 -> 30.8 us at
+            // 16, 26.3 -> 47.4 at 24 — a strip's fixed costs, layer B's 36 KB of weights above all, do not halve with its rows)
             if (g->opt_fuse & 1) {
                 if ((rc = launch_convh_pair<32, false, false>(g, 4, net.L[4], net.L[5], cur, oth, Bc, N, 0, st))) return rc;
                 std::swap(cur, oth);
@@ -2510,6 +2522,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "stop_layer")) g->opt_stop_layer = value;
 #endif
     else if (!strcmp(name, "h2_rows96")) { QGX_REQUIRE(value == 0 || value == 12 || value == 16, "h2_rows96 must be 0 (auto), 12 or 16"); g->opt_h2_rows96 = value; }
+    else if (!strcmp(name, "wino_rows64")) { QGX_REQUIRE(value == 0 || value == 4 || value == 8, "wino_rows64 must be 0 (auto), 4 or 8"); g->opt_wino_rows64 = value; }
     else if (!strcmp(name, "wino_rows96")) { QGX_REQUIRE(value == 0 || value == 12 || value == 16, "wino_rows96 must be 0 (auto), 12 or 16"); g->opt_wino_rows96 = value; }
     else if (!strcmp(name, "wino_min_tiles")) { QGX_REQUIRE(value >= 1, "wino_min_tiles must be >= 1"); g->opt_wino_min_tiles = value; }
     else if (!strcmp(name, "h2_grid")) g->opt_h2_grid = value;
