@@ -156,6 +156,10 @@ VARIANTS = [                                     # selectable variants of the pr
     dict(wino=0),                                # 5x5 layer as the 25-tap implicit GEMM instead of the 1-D Winograd form
     dict(wino_min_tiles=1),                      # ... the Winograd form at every ensemble size (64 x 64)
     dict(wino_min_tiles=1, fold=0),
+    dict(wino_rows64=4), dict(wino_rows64=8),    # tile shapes the launchers otherwise choose by tile-count quantisation
+    dict(wino_rows96=12), dict(wino_rows96=16), dict(h2_rows96=12), dict(h2_rows96=16),
+    dict(fuse96=0), dict(fuse96=3),              # 96 x 96: no pair fused / both pairs (default: layers 7 + 8)
+    dict(small_tiles=0),                         # 64 x 64, at most 4 members: the regular 4-row tiles
     dict(member_chunk=16),                       # member sub-batches
     dict(ascale_log2=3), dict(ascale_log2=-2),   # another activation pre-scale inside the window
 ]
@@ -167,7 +171,7 @@ AB_VARIANTS = [                                  # kernels of the A/B library on
     dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
 ]
 DEFAULTS = dict(fuse=3, pair=1, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h2_w8=3, ascale_log2=0, h2_x96=1, h2_w8_min96=1024,
-                wino=1, wino_min_tiles=64)
+                wino=1, wino_min_tiles=64, wino_rows64=0, wino_rows96=0, h2_rows96=0, fuse96=2, small_tiles=1)
 AB_DEFAULTS = dict(DEFAULTS, h2=3, half_nw=8, res=1, h3=0, h4=0)
 
 
@@ -184,7 +188,7 @@ def _variant_errors(gen, x, variants, defaults):
     return ref, errs
 
 
-@pytest.mark.parametrize('N,B', [(64, 32), (96, 8), (96, 32), (48, 16)])
+@pytest.mark.parametrize('N,B', [(64, 32), (96, 8), (96, 32), (48, 16), (64, 3)])
 def test_optional_kernel_variants_agree(N, B):
     """every selectable f16x3 kernel variant of the product library against the exact-f32 path: float32
     tolerance (2e-5 of the maximum); options that do not apply to a grid size fall back to the default kernels"""
@@ -202,6 +206,27 @@ def test_optional_kernel_variants_agree(N, B):
             gen.set_option('h3', 1)
         with pytest.raises(_lib.QgxError):
             gen.set_option('precision', 1)
+
+
+@pytest.mark.parametrize('N,B,opts', [(64, 16, dict(wino_rows64=[4, 8])), (64, 48, dict(wino_rows64=[4, 8])),
+                                      (96, 32, dict(wino_rows96=[12, 16], h2_rows96=[12, 16])), (96, 12, dict(wino_rows96=[12, 16], h2_rows96=[12, 16])),
+                                      (64, 1, dict(small_tiles=[0, 1])), (64, 4, dict(small_tiles=[0, 1]))])
+def test_tile_shapes_do_not_change_the_result(N, B, opts):
+    """the launchers choose tile shapes per launch by tile-count quantisation (256 persistent workgroups take ceil(tiles / 256)
+    rounds): 8- or 4-row tiles for the Winograd layer at 64 x 64, 12- or 16-row tiles at 96 x 96 (the 3x3 layers likewise, on 6 or
+    8 waves), half-height tiles for ensembles of at most 4 members.  A tile's shape does not enter any summation order, so the
+    network's output is BIT-identical whichever shape runs — a shard and the whole ensemble may pick different ones."""
+    gen = _gpu_generator('gan')
+    gen.check_range = False
+    rs = np.random.RandomState(N + 31 * B)
+    x = torch.as_tensor(rs.randn(B, 4, N, N).astype('float32'), device='cuda')
+    ref = gen.cnn_forward(x).cpu().numpy()                                   # the automatic choice
+    for name, values in opts.items():
+        for v in values:
+            gen.set_option(name, v)
+            assert np.array_equal(gen.cnn_forward(x).cpu().numpy(), ref), (name, v)
+        gen.set_option(name, 0 if name != 'small_tiles' else 1)
+    gen.close()
 
 
 def test_ab_library_variants_agree():
