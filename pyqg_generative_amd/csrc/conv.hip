@@ -841,7 +841,8 @@ struct qgx_generator {
     int opt_wino_pl = 0;           //   A/B library: 1 = channel-planar layer-1 output and the MFMA input transform (measured: see wino_planar)
     int opt_wino_exp = 0;          //   A/B library: timing experiments (conv_wino.hpp EXP)
     int opt_h2_rows96 = 0;         // 3x3 layers at 96 x 96: tile rows, 0 = by tile-count quantisation, 12 (6 waves), 16 (8 waves)
-    int opt_wino_rows64 = 0;       //   ... its tile rows at 64 x 64: 0 = by tile-count quantisation, 4, 8
+    int opt_wino_rows64 = 0;       //   ... its tile shape at 64 x 64, 128 x 128 and 32 x 32: 0 = by tile-count quantisation, 4 = the half-height
+                                   //   shape (4 x 64 tiles; 8 x 32 at 32 x 32), 8 = the full one
     int opt_wino_rows96 = 0;       //   ... its tile rows at 96 x 96: 0 = by tile-count quantisation (launch_convw), 12, 16
     int opt_wino_min_tiles = 64;   //   ... from this many 512-pixel tiles on (measured crossovers, bench_tools/ab_conv.py: 64 tiles a tie or a
                                    //   few % ahead of the 25-tap kernels on every grid, 96-144 tiles 12-28 % ahead)
@@ -1935,7 +1936,13 @@ static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int whi
     }
 #endif
     switch (N) {
-        case 32: rc = launch_convw_n<32, 32, 16>(g, layer, L, which, in, out, B, st); break;
+        case 32: {       // 16 x 32 tiles (2 per member) or 8 x 32 (4 per member): 32 / 64 members 63 -> 42 / 68 -> 49 us, 96 / 128 members stay (73 / 85, 83 / 95)
+            const int r16 = (B * 2 + 255) / 256, r8 = (B * 4 + 255) / 256;
+            const bool rows8 = g->opt_wino_rows64 == 4 || (g->opt_wino_rows64 == 0 && 0.66 * r8 < 1.0 * r16);
+            rc = rows8 ? launch_convw_n<32, 32, 8>(g, layer, L, which, in, out, B, st)
+                       : launch_convw_n<32, 32, 16>(g, layer, L, which, in, out, B, st);
+            break;
+        }
         case 48: rc = launch_convw_n<48, 16, 16>(g, layer, L, which, in, out, B, st); break;
         case 64: {
             // 8-row tiles (8 per member) or 4-row tiles (16 per member, half the work each at a 2 x instead of 1.5 x row halo): by
@@ -1958,7 +1965,14 @@ static int launch_convw(qgx_generator *g, int layer, const LayerHost &L, int whi
                         : launch_convw_n<96, 32, 16>(g, layer, L, which, in, out, B, st);
             break;
         }
-        default: rc = launch_convw_n<128, 64, 8>(g, layer, L, which, in, out, B, st); break;
+        default: {       // 128 x 128: 8 x 64 tiles (32 per member) or 4 x 64 (64 per member), as at 64 x 64: 2 / 4 members 67 -> 45 / 72 -> 53 us,
+                         // 6 / 8 members stay (78 / 89, 86 / 97), 12 members 155 -> 143
+            const int r8 = (B * 32 + 255) / 256, r4 = (B * 64 + 255) / 256;
+            const bool rows4 = g->opt_wino_rows64 == 4 || (g->opt_wino_rows64 == 0 && 0.66 * r4 < 1.0 * r8);
+            rc = rows4 ? launch_convw_n<128, 64, 4>(g, layer, L, which, in, out, B, st)
+                       : launch_convw_n<128, 64, 8>(g, layer, L, which, in, out, B, st);
+            break;
+        }
     }
     if (!rc) done = true;
     return rc;
