@@ -19,7 +19,7 @@ if 'QGX_LIB' not in os.environ and os.path.exists(_AB):
 import pyqg_generative_amd as qa
 from pyqg_generative_amd import weights
 
-OPTS = {'chunk': 32, 'last_valu': 1, 'first_split': 2, 'v3': -1, 'precision': 0, 'ascale_log2': 0, 'first_h': 1, 'half_nw': 8, 'member_chunk': 0, 'res': 1, 'h2': 3, 'pair': 1, 'fuse': 3, 'half_min_tiles': 1, 'h3': 0, 'last_rows': 0, 'part_max_tiles': 112, 'fold': 1, 'h2_grid': 0, 'h4': 0, 'prio_alt': 1, 'h2_w8': 3, 'h2_tw32': 0, 'pair_lp': 1, 'wino_pl': 0, 'wino': 1, 'wino_min_tiles': 64, 'fuse96': 2, 'wino_rows96': 0, 'h2_rows96': 0, 'small_tiles': 1, 'wino_rows64': 0}      # option -> default
+OPTS = {'chunk': 32, 'last_valu': 1, 'first_split': 2, 'v3': -1, 'precision': 0, 'ascale_log2': 0, 'first_h': 1, 'half_nw': 8, 'member_chunk': 0, 'res': 1, 'h2': 3, 'pair': 1, 'fuse': 3, 'half_min_tiles': 1, 'h3': 0, 'last_rows': 0, 'part_max_tiles': 96, 'fold': 1, 'h2_grid': 0, 'h4': 0, 'prio_alt': 1, 'h2_w8': 3, 'h2_tw32': 0, 'pair_lp': 1, 'wino_pl': 0, 'wino': 1, 'wino_min_tiles': 48, 'fuse96': 2, 'wino_rows96': 0, 'h2_rows96': 0, 'small_tiles': 1, 'wino_rows64': 0}      # option -> default
 MAC = [12800, 204800, 18432, 9216, 9216, 9216, 9216, 576]
 
 

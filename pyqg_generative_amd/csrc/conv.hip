@@ -844,10 +844,11 @@ struct qgx_generator {
     int opt_wino_rows64 = 0;       //   ... its tile shape at 64 x 64, 128 x 128 and 32 x 32: 0 = by tile-count quantisation, 4 = the half-height
                                    //   shape (4 x 64 tiles; 8 x 32 at 32 x 32), 8 = the full one
     int opt_wino_rows96 = 0;       //   ... its tile rows at 96 x 96: 0 = by tile-count quantisation (launch_convw), 12, 16
-    int opt_wino_min_tiles = 64;   //   ... from this many 512-pixel tiles on (measured crossovers, bench_tools/ab_conv.py: 64 tiles a tie or a
-                                   //   few % ahead of the 25-tap kernels on every grid, 96-144 tiles 12-28 % ahead)
+    int opt_wino_min_tiles = 48;   //   ... from this many full-height tiles on (measured crossovers, bench_tools/ab_conv.py: with the half-height
+                                   //   shapes the Winograd kernel is ahead of the 25-tap kernels from 6 members at 64 x 64, 4 at 96 x 96, 24 at 32 x 32)
     int opt_fold = 1;              // f16x3: layer 1 stores ReLU output, its BatchNorm is folded into layer 2's weights
-    int opt_part_max_tiles = 112;  // f16x3: split K on the wide layers below this many tiles (crossover: 7 members at 64x64)
+    int opt_part_max_tiles = 96;   // f16x3: split K on the wide layers below this many quarter-height tiles (crossover against the Winograd
+                                   //   layer's half-height shape: 6 members at 64 x 64 — forward 166.8 -> 158.0 us —, 4 at 96 x 96: 217.5 -> 184.3)
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
     int opt_half_min_tiles = 1;

@@ -171,7 +171,7 @@ AB_VARIANTS = [                                  # kernels of the A/B library on
     dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
 ]
 DEFAULTS = dict(fuse=3, pair=1, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h2_w8=3, ascale_log2=0, h2_x96=1, h2_w8_min96=1024,
-                wino=1, wino_min_tiles=64, wino_rows64=0, wino_rows96=0, h2_rows96=0, fuse96=2, small_tiles=1)
+                wino=1, wino_min_tiles=48, wino_rows64=0, wino_rows96=0, h2_rows96=0, fuse96=2, small_tiles=1)
 AB_DEFAULTS = dict(DEFAULTS, h2=3, half_nw=8, res=1, h3=0, h4=0)
 
 
