@@ -456,7 +456,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # Device pre-heat (NOT steps of the workload, nothing of it is timed or counted): a process that starts on an idle GPU
+    loop.run(W)
+    loop.rehearse()
+    # Device pre-heat, AFTER the warm-up steps and the rehearsal (whose host round trips leave the GPU idle for milliseconds), right
+    # before the timed region (NOT steps of the workload, nothing of it is timed or counted): a process that starts on an idle GPU
     # finds it in a low power state, and the driver's "--steps 20" timed region is 15 ms long — shorter than the clock ramp
     # (the same engine measured 6 % faster a few seconds later: `steady`).  0.3 s of generator forwards on scratch tensors.
     preheat_s = 0.0
@@ -470,8 +473,6 @@ def main():
         preheat_s = time.perf_counter() - t0
         del xs_
         gen.range_read()
-    loop.run(W)
-    loop.rehearse()
     stride = prof_stride(K)
     gen.set_option('prof_every', stride)   # HIP events around every n-th launch: each pair idles the GPU for ~12 us
     gen.profile(1)                         # dominant kernel: conv layer 2 (128->64, 5x5), 75% of the FLOPs
