@@ -27,8 +27,7 @@
 
 namespace qgx {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "conv_types.hpp"
 
 struct ConvArgs {
     const float *in;       // NHWC (B,N,N,CIN) or planar (B,CIN,N,N)
@@ -41,11 +40,12 @@ struct ConvArgs {
     unsigned *range;       // OUTH: f16x3 range guard flag word (conv_half.hpp::range_guard)
 };
 
-extern __shared__ __attribute__((aligned(16))) char conv_smem[];
-
 #include "conv_half.hpp"
 #include "conv_pair.hpp"
 #include "conv_wino.hpp"
+// conv_wino2.hip (a translation unit of its own: built without the SLP vectoriser): the same layer with the input transform
+// under the MFMAs, bit-identical to k_convw, for the tile shapes where it is faster; *done = false: take k_convw
+int launch_convw2(int N, int TW, int R, const ConvWArgs &a, int total_tiles, hipStream_t st, bool *done);
 // Kernel variants that were measured slower than the ones above (k_convh generic / plain f16, k_convh_res,
 // k_convh3 on 16x16x32 MFMAs, k_convh4 with full-line chunks) are compiled only into the A/B library
 // (`make ab` -> libqgx_ab.so, bench_tools/ab_conv.py): the product library carries one path per layer and size.
@@ -838,6 +838,7 @@ struct qgx_generator {
     int auto_wino = 0;             //   ... what calibrate_wino() decided, and the error it measured for it
     float wino_err = 0.f;
     int opt_stop_layer = 0;        //   A/B library, debugging: return after this many layers (the activation buffers keep their outputs)
+    int opt_wino2 = 1;             //   ... as k_convw2 (conv_wino2.hpp: transform under the MFMAs, bit-identical) where that kernel exists; 0 = k_convw
     int opt_wino_pl = 0;           //   A/B library: 1 = channel-planar layer-1 output and the MFMA input transform (measured: see wino_planar)
     int opt_wino_exp = 0;          //   A/B library: timing experiments (conv_wino.hpp EXP)
     int opt_h2_rows96 = 0;         // 3x3 layers at 96 x 96: tile rows, 0 = by tile-count quantisation, 12 (6 waves), 16 (8 waves)
@@ -1872,6 +1873,15 @@ static int launch_convw_n(qgx_generator *g, int layer, const LayerHost &L, int w
     const int total_tiles = B * (NN / R) * (NN / TW);
     constexpr size_t lds = convw_lds_bytes(NN, TW, R, PL);
     static_assert(lds <= 160 * 1024 - 256, "k_convw: LDS");
+    if (!PL && g->opt_wino2 && g->opt_wino_exp == 0) {
+        bool done2 = false;
+        const int rc2 = launch_convw2(NN, TW, R, a, total_tiles, st, &done2);
+        if (rc2) return rc2;
+        if (done2) {
+            if (prof_stop) QGX_HIP(hipEventRecord(prof_stop, st));
+            return QGX_OK;
+        }
+    }
     const int grid = total_tiles < 256 ? total_tiles : 256;
     void (*kern)(ConvWArgs, int) = k_convw<NN, TW, R, 0, PL>;
 #ifdef QGX_AB       // timing experiments: parts of the kernel switched off (wrong results)
@@ -2531,6 +2541,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;
     else if (!strcmp(name, "fold")) g->opt_fold = value ? 1 : 0;
     else if (!strcmp(name, "wino")) g->opt_wino = value ? 1 : 0;
+    else if (!strcmp(name, "wino2")) g->opt_wino2 = value ? 1 : 0;
 #ifdef QGX_AB
     else if (!strcmp(name, "wino_exp")) g->opt_wino_exp = value;
     else if (!strcmp(name, "wino_pl")) g->opt_wino_pl = value;

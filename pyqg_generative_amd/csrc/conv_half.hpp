@@ -29,9 +29,7 @@
 // consumed and written to LDS at the stage boundary.
 #pragma once
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// (h8, h2, u32x4, pack_h2, range_guard: conv_types.hpp)
 
 struct ConvHArgs {
     const void *in;        // [B][N][N][CIN/8][NS][8] f16
@@ -75,19 +73,6 @@ struct ConvHArgs {
         const int it_ = u * (NTHR_) + threadIdx.x;                                                           \
         if (it_ < (NUNITS)) reinterpret_cast<f32x4 *>(DST)[it_] = V[u];                                     \
     }
-
-// f16x3 range guard.  A stored activation whose hi part leaves the f16 range (|x| > 65504) becomes inf and
-// the next layer turns it into inf / NaN — or, behind a ReLU, into an innocent-looking zero.  Every epilogue
-// that stores 16-bit activations passes the largest magnitude it stored through here; an overflow raises a
-// sticky per-layer bit that qgx_generator_range_read reports (the facade re-runs in exact f32 / aborts).
-__device__ __forceinline__ void range_guard(float mx, unsigned *range, unsigned bit) {
-    if (mx > 65504.f) atomicOr(range, bit);
-}
-
-__device__ __forceinline__ unsigned pack_h2(float a, float b) {
-    h2 v = {(_Float16)a, (_Float16)b};
-    return __builtin_bit_cast(unsigned, v);
-}
 
 // Epilogue of one 32(out channels) x 32(pixels) accumulator tile in the swapped-role layout:
 // lane (li, h) owns pixel li; register r holds output channel cb + (r & 3) + 8 (r >> 2) + 4 h.
