@@ -156,12 +156,17 @@ def prof_stride(K):
 
 
 def layer2_kernel(gen, precision, N, B):
-    """(name of the kernel that runs generator layer 2 for this generator / shard, executed f16 MFMA flops per algorithmic flop)"""
-    if precision == 'f32':
+    """(name of the kernel that runs generator layer 2 for this generator / shard, executed f16 MFMA flops per algorithmic flop):
+    asked of the library (qgx_generator_layer2_kernel), which applies its own crossovers"""
+    k = gen.layer2_kernel(B, N)
+    if k == 0:
         return 'k_conv<128,64,5x5>', None
-    tiles = {32: 2, 48: 9, 64: 8, 96: 18, 128: 32}.get(N, 0) * B
-    if gen.wino_info()['enabled'] and tiles >= 128:
+    if k == 4:
+        return 'k_convw2 (1-D Winograd F(4,5) along x, f16x3, input transform under the MFMAs)', 3 * 0.4
+    if k == 3:
         return 'k_convw (1-D Winograd F(4,5) along x, f16x3)', 3 * 0.4
+    if k == 2:
+        return 'k_convh2<128,64,5x5,PART> (25 taps, split-K, f16x3)', 3.0
     return 'k_convh2<128,64,5x5> (25 taps, f16x3)', 3.0
 
 

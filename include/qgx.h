@@ -259,6 +259,14 @@ int qgx_generator_info(const qgx_generator *g, int *precision, int *ascale_log2,
  * generator only if, at qgx_generator_create, its outputs on calibration inputs stayed within 1e-5 of the exact-f32 kernels'
  * (relative to the largest output).  -> whether it is in use, what calibration decided, and the error it measured. */
 int qgx_generator_wino_info(const qgx_generator *g, int *enabled, int *chosen_by_calibration, float *calibration_error);
+/* ... the same per grid size: the calibration is made at every size the kernels are specialised for (32, 48, 64, 96, 128 — the
+ * tile shapes differ between them) and the form is admitted size by size; _wino_info reports the 64 x 64 entry.  Another N:
+ * enabled = 0, error = inf.  (No reference counterpart; the arithmetic it guards is cnn_tools.py:79-98,125-176.) */
+int qgx_generator_wino_info_n(const qgx_generator *g, int N, int *enabled, int *chosen_by_calibration, float *calibration_error);
+/* Which kernel the 5x5 layer of net `inet` takes for B members at N x N under the options in force: 0 exact-f32 MFMA, 1 the
+ * 25-tap f16x3 kernel, 2 its split-K form (tiny ensembles), 3 1-D Winograd (k_convw), 4 1-D Winograd with the input transform
+ * under the MFMAs (k_convw2).  For measurement code (bench.py's roofline names the kernel it times). */
+int qgx_generator_layer2_kernel(const qgx_generator *g, int inet, int B, int N, int *kernel);
 int qgx_generator_profile(qgx_generator *g, int layer);
 int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches);
 

@@ -88,6 +88,8 @@ SYMBOLS = [
     ('qgx_generator_info', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_float)]),
     ('qgx_generator_wino_info', C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    ('qgx_generator_wino_info_n', C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    ('qgx_generator_layer2_kernel', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ('qgx_generator_profile', C.c_int, [C.c_void_p, C.c_int]),
     ('qgx_generator_profile_read', C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     ('qgx_noise_normal', C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64,

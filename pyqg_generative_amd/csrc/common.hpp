@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 #include <string>
+#include <memory>
 #include "../../include/qgx.h"
 
 namespace qgx {
@@ -39,6 +40,10 @@ void set_error(const char *fmt, ...);
             qgx::set_error("%s: the handle is an FFT plan only (created with plan_only), it has no model state", what); \
             return QGX_ERR_STATE;                                                          \
         }                                                                                  \
+        if ((m) && !(m)->broken.empty()) {                                                 \
+            qgx::set_error("%s: the model state is invalid: %s", what, (m)->broken.c_str()); \
+            return QGX_ERR_STATE;                                                          \
+        }                                                                                  \
     } while (0)
 
 constexpr int MAX_RADIX_PASSES = 12;
@@ -56,6 +61,7 @@ struct ModelOpts {
     int team = 1;                // 256 x 256: XCD-resident runs of unparameterized steps
     int team_min = 2;            //   shortest run handed to that kernel
     int team_fault = 0;          //   A/B library only: raise the run kernel's flag at the end of the next run (test hook)
+    int step_fault = 0;          //   A/B library only: half-ensemble (1 | 2) of a two-stream qgx_step refuses its second chunk (test hook)
     int large_fused = 1;         // large grids: fused row / column kernels (0: one launch per pass and pointwise phase)
     int large_lazy_q = 1;        // large grids: unparameterized steps keep no real-space q
     int large_specialised = 1;   // large grids: compile-time-N kernels at 128 / 256 / 512
@@ -144,7 +150,12 @@ struct qgx_model {
     double *t_filtr = nullptr, *t_wv2 = nullptr, *t_a = nullptr, *t_kk = nullptr, *t_ll = nullptr;
     double2 *t_tw = nullptr;
     int *t_pos = nullptr;
-    std::vector<double> h_filtr, h_wv2, h_a, h_kk, h_ll;
+    // (behind one pointer: qgx_step copies the model's bookkeeping for its two half-ensembles on every call)
+    struct HostTables { std::vector<double> filtr, wv2, a, kk, ll; };
+    std::shared_ptr<HostTables> host;
+    // a step that failed half-way (one half-ensemble advanced, the other not; a stream operation refused after the fork) leaves
+    // device buffers and bookkeeping out of step: every later call on the handle fails loudly with this message
+    std::string broken;
     // state (device)
     double *q = nullptr, *u = nullptr, *v = nullptr, *S = nullptr;
     double2 *qh[2] = {nullptr, nullptr};   // ping-pong; qh[cur_q] is current

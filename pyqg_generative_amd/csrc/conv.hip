@@ -834,9 +834,10 @@ struct qgx_generator {
     int opt_prio_alt = 1;          // k_convh2 with two workgroups per CU: alternate their wave priority per tile
     int opt_h4 = 0;                // 5x5 layer: k_convh4 (full-line patch chunks, 8 waves, R = 8)
     int opt_h2_grid = 0;           // k_convh2: persistent workgroups per launch (0 = one or two per CU by LDS size)
-    int opt_wino = 1;              // f16x3, 64 x 64: the 5x5 layer as a 1-D Winograd convolution F(4, 5) along x (k_convw)
-    int auto_wino = 0;             //   ... what calibrate_wino() decided, and the error it measured for it
-    float wino_err = 0.f;
+    int opt_wino = 2;              // f16x3: the 5x5 layer as a 1-D Winograd convolution F(4, 5) along x (k_convw): 0 never, 1 on every
+                                   //   specialised grid, 2 = per grid size, where calibrate_wino() admitted it
+    int auto_wino_n[5] = {0, 0, 0, 0, 0};            //   ... what calibrate_wino() decided for N = 32, 48, 64, 96, 128 and the errors it measured
+    float wino_err_n[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     int opt_stop_layer = 0;        //   A/B library, debugging: return after this many layers (the activation buffers keep their outputs)
     int opt_wino2 = 1;             //   ... as k_convw2 (conv_wino2.hpp: transform under the MFMAs, bit-identical) where that kernel exists; 0 = k_convw
     int opt_wino_pl = 0;           //   A/B library: 1 = channel-planar layer-1 output and the MFMA input transform (measured: see wino_planar)
@@ -1912,9 +1913,13 @@ static int wino_tiles(int B, int N) {
 }
 // does the 5x5 layer run as the Winograd form for this ensemble?  (decided BEFORE layer 1: its output layout — channel-planar
 // for the MFMA input transform — and its range guard depend on it)
+static int wino_size_index(int N) {
+    switch (N) { case 32: return 0; case 48: return 1; case 64: return 2; case 96: return 3; case 128: return 4; default: return -1; }
+}
 static bool wino_applies(const qgx_generator *g, const LayerHost &L, int which, int B, int N) {
-    const int tiles = wino_tiles(B, N);
-    return g->opt_wino && L.ww[which] && tiles > 0 && tiles >= g->opt_wino_min_tiles;
+    const int tiles = wino_tiles(B, N), si = wino_size_index(N);
+    const bool on = g->opt_wino == 1 || (g->opt_wino == 2 && si >= 0 && g->auto_wino_n[si]);
+    return on && L.ww[which] && tiles > 0 && tiles >= g->opt_wino_min_tiles;
 }
 // A/B library only: layer 1 stores channel-planar rows and the Winograd layer's input transform runs on the matrix cores
 // (conv_wino.hpp PL).  Measured against the product's pixel-major form (bench_tools/ab_conv.py, wino_pl): 64 x 64 / 128 members
@@ -2201,61 +2206,75 @@ static int cnn_forward(qgx_generator *g, const NetHost &net, const float *x, flo
 // accumulators carry the condition of the Toom-Cook matrices: for the layer, 3-4 x the rounding error of the 25-tap form
 // (float32 evaluation of both: tests/test_conv_transform_numerics_cpu.py), and how much of that reaches the net's output
 // depends on the weights behind it (shipped nets: 3e-6 ... 9e-6 of max|y|; random-weight nets up to 5e-5).  So it is
-// MEASURED per generator: every net is evaluated at 64 x 64 on calibration inputs (white noise, one member hotter; smooth
-// fields; constants) with the Winograd layer and with the exact-f32 kernels, and the Winograd form becomes the default only
-// if the largest difference stays below WINO_MAX_ERR of the largest output — half of the tolerance the golden vectors are
-// held to.  (qgx_generator_wino_info reports the decision; option "wino" overrides it.)
+// MEASURED per generator AND per grid size it is specialised for (32, 48, 64, 96, 128: the tile shapes, and with them the
+// rows and quads a workgroup transforms together, differ between them): every net is evaluated on calibration inputs
+// (white noise, one member hotter; smooth fields; constants) with the Winograd layer and with the exact-f32 kernels, and
+// the Winograd form becomes the default AT THAT SIZE only if the largest difference stays below WINO_MAX_ERR of the
+// largest output — half of the tolerance the golden vectors are held to.  (qgx_generator_wino_info_n reports the decision
+// per size; option "wino" = 0 / 1 overrides it, 2 restores it.)  The two tile shapes a size may run in (full / half
+// height) give bit-identical results, as do k_convw and k_convw2: one evaluation per size covers them.
 static constexpr float WINO_MAX_ERR = 1e-5f;
 static int calibrate_wino(qgx_generator *g) {
-    g->auto_wino = 0; g->wino_err = 0.f; g->opt_wino = 0;
+    for (int i = 0; i < 5; ++i) { g->auto_wino_n[i] = 0; g->wino_err_n[i] = 0.f; }
+    g->opt_wino = 0;
     if (g->opt_precision != 3) return QGX_OK;
-    const int N = 64, B = 8, npix = N * N;
-    int rc = reserve(g, B, N);
-    if (rc) return rc;
+    static const int SIZES[5] = {32, 48, 64, 96, 128};
     unsigned *cd = nullptr;
     QGX_HIP(hipMalloc((void **)&cd, 2 * sizeof(unsigned)));
-    QGX_HIP(hipMemset(cd, 0, 2 * sizeof(unsigned)));
     const int saved_part = g->opt_part_max_tiles, saved_min = g->opt_wino_min_tiles;
-    float worst = 0.f;
-    for (int n = 0; n < g->n_nets && !rc; ++n) {
-        const NetHost &net = g->nets[n];
-        if (!net.L[1].ww[0]) { worst = INFINITY; break; }
-        std::vector<float> x((size_t)B * net.n_in * npix);
-        uint32_t lcg = 54321u + 977u * n;
-        auto uni = [&]() { lcg = lcg * 1664525u + 1013904223u; return ((lcg >> 8) + 0.5f) * (1.0f / 16777216.0f); };
-        for (int b = 0; b < B; ++b)
-            for (int c = 0; c < net.n_in; ++c)
-                for (int y = 0; y < N; ++y)
-                    for (int xx = 0; xx < N; ++xx) {
-                        float v;
-                        const float white = sqrtf(-2.f * logf(uni())) * cosf(6.2831853f * uni());
-                        if (b < 5) v = white * (b == 3 ? 2.f : (b == 4 ? 1.5f : 1.f));
-                        else if (b < 7) v = 2.f * sinf(6.2831853f * (y * (c + 1) + xx * (b - 4)) / N)
-                                            + cosf(6.2831853f * 2 * xx / N) + 0.3f * white;
-                        else v = 3.f * ((c & 1) ? -1.f : 1.f);
-                        x[(((size_t)b * net.n_in + c) * N + y) * N + xx] = v;
-                    }
-        QGX_HIP(hipMemcpy(g->X, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice));
-        g->opt_precision = 0;
-        rc = cnn_forward(g, net, g->X, g->Y0, B, N, nullptr);
-        g->opt_precision = 3; g->opt_wino = 1; g->opt_wino_min_tiles = 1; g->opt_part_max_tiles = 0;
-        if (!rc) rc = cnn_forward(g, net, g->X, g->Y1, B, N, nullptr);
-        g->opt_wino = 0; g->opt_wino_min_tiles = saved_min; g->opt_part_max_tiles = saved_part;
+    int rc = QGX_OK;
+    for (int si = 0; si < 5 && !rc; ++si) {
+        const int N = SIZES[si], npix = N * N;
+        // as many members as keep the workspace of the calibration at what eight 64 x 64 members need (2 at 128 x 128)
+        const int B = N <= 64 ? 8 : (N == 96 ? 4 : 2);
+        // member patterns: 0-2 white noise, 3 white x 2, 4 white x 1.5, 5-6 smooth large-scale fields + noise, 7 constants;
+        // with fewer than eight members the hot, the smooth and the constant ones come first
+        static const int PAT8[8] = {0, 1, 2, 3, 4, 5, 6, 7}, PAT4[4] = {3, 5, 7, 0}, PAT2[2] = {3, 5};
+        const int *pat = B == 8 ? PAT8 : (B == 4 ? PAT4 : PAT2);
+        rc = reserve(g, B, N);
         if (rc) break;
-        QGX_HIP(hipMemset(cd, 0, 2 * sizeof(unsigned)));
-        hipLaunchKernelGGL(k_absdiff_max, dim3(64), dim3(256), 0, nullptr, (const float *)g->Y1, (const float *)g->Y0,
-                           (size_t)B * net.n_out * npix, cd);
-        float h[2];
-        QGX_HIP(hipMemcpy(h, cd, sizeof(h), hipMemcpyDeviceToHost));
-        const float err = h[1] > 0.f ? h[0] / h[1] : INFINITY;
-        worst = fmaxf(worst, std::isfinite(err) ? err : INFINITY);
+        float worst = 0.f;
+        for (int n = 0; n < g->n_nets && !rc; ++n) {
+            const NetHost &net = g->nets[n];
+            if (!net.L[1].ww[0]) { worst = INFINITY; break; }
+            std::vector<float> x((size_t)B * net.n_in * npix);
+            uint32_t lcg = 54321u + 977u * n;
+            auto uni = [&]() { lcg = lcg * 1664525u + 1013904223u; return ((lcg >> 8) + 0.5f) * (1.0f / 16777216.0f); };
+            for (int b = 0; b < B; ++b)
+                for (int c = 0; c < net.n_in; ++c)
+                    for (int y = 0; y < N; ++y)
+                        for (int xx = 0; xx < N; ++xx) {
+                            float v;
+                            const int pb = pat[b];
+                            const float white = sqrtf(-2.f * logf(uni())) * cosf(6.2831853f * uni());
+                            if (pb < 5) v = white * (pb == 3 ? 2.f : (pb == 4 ? 1.5f : 1.f));
+                            else if (pb < 7) v = 2.f * sinf(6.2831853f * (y * (c + 1) + xx * (pb - 4)) / N)
+                                                 + cosf(6.2831853f * 2 * xx / N) + 0.3f * white;
+                            else v = 3.f * ((c & 1) ? -1.f : 1.f);
+                            x[(((size_t)b * net.n_in + c) * N + y) * N + xx] = v;
+                        }
+            QGX_HIP(hipMemcpy(g->X, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice));
+            g->opt_precision = 0;
+            rc = cnn_forward(g, net, g->X, g->Y0, B, N, nullptr);
+            g->opt_precision = 3; g->opt_wino = 1; g->opt_wino_min_tiles = 1; g->opt_part_max_tiles = 0;
+            if (!rc) rc = cnn_forward(g, net, g->X, g->Y1, B, N, nullptr);
+            g->opt_wino = 0; g->opt_wino_min_tiles = saved_min; g->opt_part_max_tiles = saved_part;
+            if (rc) break;
+            QGX_HIP(hipMemset(cd, 0, 2 * sizeof(unsigned)));
+            hipLaunchKernelGGL(k_absdiff_max, dim3(64), dim3(256), 0, nullptr, (const float *)g->Y1, (const float *)g->Y0,
+                               (size_t)B * net.n_out * npix, cd);
+            float h[2];
+            QGX_HIP(hipMemcpy(h, cd, sizeof(h), hipMemcpyDeviceToHost));
+            const float err = h[1] > 0.f ? h[0] / h[1] : INFINITY;
+            worst = fmaxf(worst, std::isfinite(err) ? err : INFINITY);
+        }
+        g->wino_err_n[si] = worst;
+        g->auto_wino_n[si] = !rc && worst <= WINO_MAX_ERR ? 1 : 0;
     }
     (void)hipFree(cd);
     QGX_HIP(hipMemset(g->range_dev, 0, 2 * sizeof(unsigned)));     // the calibration runs are not the caller's
     if (rc) return rc;
-    g->wino_err = worst;
-    g->auto_wino = worst <= WINO_MAX_ERR ? 1 : 0;
-    g->opt_wino = g->auto_wino;
+    g->opt_wino = 2;
     return QGX_OK;
 }
 
@@ -2434,11 +2453,46 @@ extern "C" int qgx_generator_range_read(qgx_generator *g, unsigned *flags, float
     return QGX_OK;
 }
 
+extern "C" int qgx_generator_wino_info_n(const qgx_generator *g, int N, int *enabled, int *chosen_by_calibration, float *calibration_error) {
+    QGX_REQUIRE(g, "qgx_generator_wino_info_n: null generator");
+    const int si = wino_size_index(N);
+    if (enabled) *enabled = si >= 0 && (g->opt_wino == 1 || (g->opt_wino == 2 && g->auto_wino_n[si]));
+    if (chosen_by_calibration) *chosen_by_calibration = si >= 0 ? g->auto_wino_n[si] : 0;
+    if (calibration_error) *calibration_error = si >= 0 ? g->wino_err_n[si] : INFINITY;
+    return QGX_OK;
+}
+
+// which kernel the 5x5 layer (layer 2) of net `inet` takes for an ensemble of B members at N x N with the options in
+// force: 0 exact-f32 MFMA, 1 the 25-tap f16x3 kernel, 2 its split-K form (tiny ensembles), 3 1-D Winograd (k_convw),
+// 4 1-D Winograd with the transform under the MFMAs (k_convw2).  Mirrors cnn_forward_half / launch_convw.
+extern "C" int qgx_generator_layer2_kernel(const qgx_generator *g, int inet, int B, int N, int *kernel) {
+    QGX_REQUIRE(g && kernel, "qgx_generator_layer2_kernel: null argument");
+    QGX_REQUIRE(inet >= 0 && inet < g->n_nets, "qgx_generator_layer2_kernel: net %d of %d", inet, g->n_nets);
+    const NetHost &net = g->nets[inet];
+    *kernel = 0;
+    if (g->opt_precision != 3 || rows_h2(N) <= 0) return QGX_OK;
+    const bool fold = g->opt_first_h && g->opt_fold && net.L[1].whF;
+    const int r2 = rows_h2(N);
+    const bool tiny = g->opt_h2 == 3 && r2 > 0 && B * (N / r2) < g->opt_part_max_tiles;
+    if (tiny) { *kernel = 2; return QGX_OK; }
+    *kernel = 1;
+    if (g->opt_first_h && wino_applies(g, net.L[1], fold ? 1 : 0, B, N)) {
+        *kernel = 3;
+        if (g->opt_wino2 && !wino_planar(g) && g->opt_wino_exp == 0) {
+            bool rows_full = true;       // the full-height shape of launch_convw (k_convw2 exists for it at 64 x 64 and as 12 rows at 96 x 96)
+            if (N == 64) { const int r8 = (B * 8 + 255) / 256, r4 = (B * 16 + 255) / 256; rows_full = !(g->opt_wino_rows64 == 4 || (g->opt_wino_rows64 == 0 && 0.66 * r4 < 1.0 * r8)); if (rows_full) *kernel = 4; }
+            else if (N == 96) { const int r16 = (B * 18 + 255) / 256, r12 = (B * 24 + 255) / 256; if (g->opt_wino_rows96 == 12 || (g->opt_wino_rows96 == 0 && 0.79 * r12 < 1.0 * r16)) *kernel = 4; }
+        }
+    }
+    return QGX_OK;
+}
+
 extern "C" int qgx_generator_wino_info(const qgx_generator *g, int *enabled, int *chosen_by_calibration, float *calibration_error) {
     QGX_REQUIRE(g, "qgx_generator_wino_info: null generator");
-    if (enabled) *enabled = g->opt_wino;
-    if (chosen_by_calibration) *chosen_by_calibration = g->auto_wino;
-    if (calibration_error) *calibration_error = g->wino_err;
+    // the 64 x 64 grid (the headline workload); qgx_generator_wino_info_n reports every size
+    if (enabled) *enabled = g->opt_wino == 1 || (g->opt_wino == 2 && g->auto_wino_n[2]);
+    if (chosen_by_calibration) *chosen_by_calibration = g->auto_wino_n[2];
+    if (calibration_error) *calibration_error = g->wino_err_n[2];
     return QGX_OK;
 }
 
@@ -2540,7 +2594,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "last_rows")) g->opt_last_rows = value;
     else if (!strcmp(name, "part_max_tiles")) g->opt_part_max_tiles = value;
     else if (!strcmp(name, "fold")) g->opt_fold = value ? 1 : 0;
-    else if (!strcmp(name, "wino")) g->opt_wino = value ? 1 : 0;
+    else if (!strcmp(name, "wino")) { QGX_REQUIRE(value >= 0 && value <= 2, "wino must be 0 (never), 1 (every specialised grid) or 2 (per grid size, as calibrated)"); g->opt_wino = value; }
     else if (!strcmp(name, "wino2")) g->opt_wino2 = value ? 1 : 0;
 #ifdef QGX_AB
     else if (!strcmp(name, "wino_exp")) g->opt_wino_exp = value;
@@ -2563,7 +2617,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "half_nw")) { QGX_REQUIRE(value == 4 || value == 8, "half_nw must be 4 or 8"); g->opt_half_nw = value; }
     else if (!strcmp(name, "ascale_log2")) { QGX_REQUIRE(value >= -24 && value <= 24, "ascale_log2 must be in -24..24"); g->opt_ascale = ldexpf(1.f, value); }
     else if (!strcmp(name, "prof_every")) { QGX_REQUIRE(value >= 1, "prof_every must be >= 1"); g->prof_every = value; }
-    else if (!strcmp(name, "auto")) { g->opt_precision = g->auto_precision; g->opt_fold = g->auto_fold; g->opt_ascale = ldexpf(1.f, g->auto_ascale_log2); g->opt_wino = g->auto_wino; }
+    else if (!strcmp(name, "auto")) { g->opt_precision = g->auto_precision; g->opt_fold = g->auto_fold; g->opt_ascale = ldexpf(1.f, g->auto_ascale_log2); g->opt_wino = 2; }
     else if (!strcmp(name, "first_split")) { QGX_REQUIRE(value == 1 || value == 2 || value == 4, "first_split must be 1, 2 or 4"); g->opt_first_split = value; }
     else QGX_REQUIRE(false, "unknown generator option '%s'", name);
     return QGX_OK;

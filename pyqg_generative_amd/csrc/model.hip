@@ -88,11 +88,10 @@ static int model_step_run(qgx_model *m, int K, hipStream_t st) {
 // (its bounded waits timed out because other work held CUs, or its workgroups were not co-resident) left its inputs
 // intact: the bookkeeping is restored, the kernel is switched off for this model and the K steps are replayed on the
 // three-launch path — a long run degrades, it is not lost.  qgx_run_kernel_state() reports -1 afterwards.
-static int team_settle(qgx_model *m, hipStream_t st) {
+static int team_settle(qgx_model *m, hipStream_t caller) {
     if (!m || m->small || !m->team_pending) return QGX_OK;
     unsigned flag = 0;
-    (void)st;
-    st = m->team_stream;                 // the run's own stream: the read-back and the replay are ordered behind it
+    hipStream_t st = m->team_stream;     // the run's own stream: the read-back and the replay are ordered behind it
     int rc = large_team_check(m, st, &flag);
     if (rc) return rc;
     const qgx_model::TeamUndo u = m->team_undo;
@@ -105,6 +104,9 @@ static int team_settle(qgx_model *m, hipStream_t st) {
     m->tc = u.tc; m->ablevel = u.ablevel; m->uv_stale = u.uv_stale; m->q_stale = u.q_stale;
     for (int s = 0; s < u.K; ++s)
         if ((rc = model_step_once(m, false, nullptr, 1.0, 0, 0, st))) return rc;
+    // the entry point that settles may work on another stream than the run was launched on: what it enqueues next (a copy out
+    // of the state, a kernel that overwrites it) must not overtake the replayed steps.  A replay is the rare path: wait for it.
+    if (caller != st) QGX_HIP(hipStreamSynchronize(st));
     return QGX_OK;
 }
 
@@ -203,11 +205,12 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
 
     // pyqg model.py::_initialize_grid
     const double dk = 2. * pi / L, dl = 2. * pi / W;
-    m->h_kk.resize(NK); m->h_ll.resize(N);
-    for (int i = 0; i < NK; ++i) m->h_kk[i] = dk * (double)i;
-    for (int j = 0; j < N; ++j) m->h_ll[j] = dl * (double)(j < N / 2 ? j : j - N);
+    m->host = std::make_shared<qgx_model::HostTables>();
+    m->host->kk.resize(NK); m->host->ll.resize(N);
+    for (int i = 0; i < NK; ++i) m->host->kk[i] = dk * (double)i;
+    for (int j = 0; j < N; ++j) m->host->ll[j] = dl * (double)(j < N / 2 ? j : j - N);
     const double dx = L / N, dy = W / N;
-    m->h_wv2.resize((size_t)N * NK); m->h_filtr.resize((size_t)N * NK); m->h_a.resize((size_t)4 * N * NK);
+    m->host->wv2.resize((size_t)N * NK); m->host->filtr.resize((size_t)N * NK); m->host->a.resize((size_t)4 * N * NK);
     // pyqg qg_model.py::_initialize_background
     const double F1 = pow(cfg->rd, -2.0) / (1. + cfg->delta);
     const double F2 = cfg->delta * F1;
@@ -217,21 +220,21 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
     const size_t sz = (size_t)N * NK;
     for (int j = 0; j < N; ++j)
         for (int i = 0; i < NK; ++i) {
-            const double k = m->h_kk[i], l = m->h_ll[j];
+            const double k = m->host->kk[i], l = m->host->ll[j];
             const double wv2 = k * k + l * l;
             const size_t o = (size_t)j * NK + i;
-            m->h_wv2[o] = wv2;
+            m->host->wv2[o] = wv2;
             // model.py::_initialize_filter
             const double wvx = sqrt((k * dx) * (k * dx) + (l * dy) * (l * dy));
-            m->h_filtr[o] = wvx <= cphi ? 1.0 : exp(-cfg->filterfac * pow(wvx - cphi, 4.));
+            m->host->filtr[o] = wvx <= cphi ? 1.0 : exp(-cfg->filterfac * pow(wvx - cphi, 4.));
             // qg_model.py::_initialize_inversion_matrix
             const double det = wv2 * (wv2 + F1 + F2);
             const double det_inv = det != 0. ? 1.0 / det : 0.;
-            m->h_a[0 * sz + o] = -(wv2 + F2) * det_inv;
-            m->h_a[1 * sz + o] = -F1 * det_inv;
-            m->h_a[2 * sz + o] = -F2 * det_inv;
-            m->h_a[3 * sz + o] = -(wv2 + F1) * det_inv;
-            if (det == 0.) for (int t = 0; t < 4; ++t) m->h_a[t * sz + o] = 0.;
+            m->host->a[0 * sz + o] = -(wv2 + F2) * det_inv;
+            m->host->a[1 * sz + o] = -F1 * det_inv;
+            m->host->a[2 * sz + o] = -F2 * det_inv;
+            m->host->a[3 * sz + o] = -(wv2 + F1) * det_inv;
+            if (det == 0.) for (int t = 0; t < 4; ++t) m->host->a[t * sz + o] = 0.;
         }
     // twiddles and the digit-reversal map of the DIF passes
     std::vector<double2> tw(N);
@@ -252,9 +255,9 @@ extern "C" int qgx_create(const qgx_config *cfg, qgx_model **out) {
         pos[kf] = P;
     }
     int rc;
-    if ((rc = upload(m->t_filtr, m->h_filtr)) || (rc = upload(m->t_wv2, m->h_wv2)) ||
-        (rc = upload(m->t_a, m->h_a)) || (rc = upload(m->t_kk, m->h_kk)) ||
-        (rc = upload(m->t_ll, m->h_ll)) || (rc = upload(m->t_tw, tw)) || (rc = upload(m->t_pos, pos))) {
+    if ((rc = upload(m->t_filtr, m->host->filtr)) || (rc = upload(m->t_wv2, m->host->wv2)) ||
+        (rc = upload(m->t_a, m->host->a)) || (rc = upload(m->t_kk, m->host->kk)) ||
+        (rc = upload(m->t_ll, m->host->ll)) || (rc = upload(m->t_tw, tw)) || (rc = upload(m->t_pos, pos))) {
         qgx_destroy(m);
         return rc;
     }
@@ -364,11 +367,11 @@ extern "C" int qgx_get_table(qgx_model *m, int table, double *out) {
     QGX_REQUIRE(m && out, "qgx_get_table: null argument");
     const std::vector<double> *v = nullptr;
     switch (table) {
-        case QGX_T_FILTR: v = &m->h_filtr; break;
-        case QGX_T_WV2: v = &m->h_wv2; break;
-        case QGX_T_A: v = &m->h_a; break;
-        case QGX_T_KK: v = &m->h_kk; break;
-        case QGX_T_LL: v = &m->h_ll; break;
+        case QGX_T_FILTR: v = &m->host->filtr; break;
+        case QGX_T_WV2: v = &m->host->wv2; break;
+        case QGX_T_A: v = &m->host->a; break;
+        case QGX_T_KK: v = &m->host->kk; break;
+        case QGX_T_LL: v = &m->host->ll; break;
         default: QGX_REQUIRE(false, "qgx_get_table: unknown table %d", table);
     }
     memcpy(out, v->data(), v->size() * sizeof(double));
@@ -424,6 +427,14 @@ extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
         o.team_fault = value ? 1 : 0;
 #else
         QGX_REQUIRE(false, "option 'team_fault' is a test hook of the A/B library only (make ab, QGX_LIB=libqgx_ab.so)");
+#endif
+    }
+    else if (!strcmp(name, "step_fault")) {
+#ifdef QGX_AB
+        QGX_REQUIRE(value >= 0 && value <= 2, "step_fault must be 0, 1 or 2");
+        o.step_fault = value;
+#else
+        QGX_REQUIRE(false, "option 'step_fault' is a test hook of the A/B library only (make ab, QGX_LIB=libqgx_ab.so)");
 #endif
     }
     else if (!strcmp(name, "large_fused")) o.large_fused = value ? 1 : 0;
@@ -609,14 +620,19 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
     for (int i = 0; i < 2; ++i) if (!m->sub_stream[i]) QGX_HIP(hipStreamCreateWithFlags(&m->sub_stream[i], hipStreamNonBlocking));
     for (int i = 0; i < 3; ++i) if (!m->sub_event[i]) QGX_HIP(hipEventCreateWithFlags(&m->sub_event[i], hipEventDisableTiming));
     if (m->dg_every > 0) { int arc = diag_ensure_alloc(m); if (arc) return arc; }   // BEFORE the children copy the pointers
-    // fork
+    // fork.  From here on every exit runs the join below: the caller's stream is ordered behind whatever the sub-streams
+    // were given, and a step that failed half-way leaves the handle marked invalid (the halves may stand at different
+    // steps, the parent's bookkeeping at neither): later calls fail loudly instead of stepping from an inconsistent state.
     QGX_HIP(hipEventRecord(m->sub_event[2], st));
     qgx_model child[2] = {*m, *m};
     qgx_param pp[2] = {*p, *p};
     const size_t sr = (size_t)2 * N * N, ss = (size_t)2 * N * NK, s2 = (size_t)N * NK;
     const size_t zbytes = generator_noise_is_double(p->gen) ? sizeof(double) : sizeof(float);
+    int rc = QGX_OK;
+    hipError_t herr = hipSuccess;
+    const char *hwhat = "";
     for (int c = 0; c < 2; ++c) {
-        QGX_HIP(hipStreamWaitEvent(m->sub_stream[c], m->sub_event[2], 0));
+        if (herr == hipSuccess && (herr = hipStreamWaitEvent(m->sub_stream[c], m->sub_event[2], 0)) != hipSuccess) hwhat = "hipStreamWaitEvent (fork)";
         qgx_model &k = child[c];
         const size_t b0 = (size_t)c * Bp;
         k.B = Bp; k.d.B = Bp;
@@ -637,22 +653,47 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
     // the halves take turns in chunks of steps (a chunk keeps the fused input / output kernels of consecutive steps fused and
     // both streams fed: the host enqueues a chunk in a fraction of the time the GPU needs for it)
     constexpr int CHUNK = 8;
-    int rc = QGX_OK;
-    for (int s0 = 0; s0 < nsteps && !rc; s0 += CHUNK) {
+    bool advanced = false;
+    for (int s0 = 0; s0 < nsteps && !rc && herr == hipSuccess; s0 += CHUNK) {
         const int n = nsteps - s0 < CHUNK ? nsteps - s0 : CHUNK;
         const int refresh = refresh_diag && s0 + n == nsteps;
         for (int c = 0; c < 2 && !rc; ++c) {
             if ((rc = generator_select_workspace(p->gen, c))) break;
+#ifdef QGX_AB
+            if (m->opts.step_fault == 1 + c && s0 >= CHUNK) {        // test hook (A/B library only): this half refuses its second chunk
+                qgx::set_error("qgx_step: injected failure of half %d (option step_fault)", c);
+                rc = QGX_ERR_HIP;
+                break;
+            }
+#endif
             rc = step_core(&child[c], n, &pp[c], refresh, m->sub_stream[c]);
+            advanced = true;
         }
     }
     (void)generator_select_workspace(p->gen, 0);
-    // join
+    // join (best effort on every path: an error here is reported, but never skips the other stream)
     for (int c = 0; c < 2; ++c) {
-        QGX_HIP(hipEventRecord(m->sub_event[c], m->sub_stream[c]));
-        QGX_HIP(hipStreamWaitEvent(st, m->sub_event[c], 0));
+        hipError_t e1 = hipEventRecord(m->sub_event[c], m->sub_stream[c]);
+        if (e1 == hipSuccess) e1 = hipStreamWaitEvent(st, m->sub_event[c], 0);
+        if (e1 != hipSuccess && herr == hipSuccess) { herr = e1; hwhat = "join of the half-ensemble streams"; }
     }
-    if (rc) return rc;
+    if (herr != hipSuccess) {
+        // the caller's stream could not be ordered behind the halves: wait for them here, so that nothing the caller
+        // enqueues next can overtake them
+        (void)hipStreamSynchronize(m->sub_stream[0]);
+        (void)hipStreamSynchronize(m->sub_stream[1]);
+        qgx::set_error("qgx_step: %s failed: %s", hwhat, hipGetErrorString(herr));
+        if (!rc) rc = QGX_ERR_HIP;
+    }
+    if (rc) {
+        if (advanced) {
+            const std::string why = qgx_last_error();
+            m->broken = "a step of two half-ensembles failed half-way (" + why + "); the halves are at steps " +
+                        std::to_string((long long)child[0].tc) + " and " + std::to_string((long long)child[1].tc) +
+                        "; destroy the handle";
+        }
+        return rc;
+    }
     // the halves advanced in lockstep: the bookkeeping of either is the ensemble's
     const qgx_model &k = child[0];
     QGX_REQUIRE(k.tc == child[1].tc && k.cur_q == child[1].cur_q && k.i_new == child[1].i_new && k.noise_step == child[1].noise_step &&

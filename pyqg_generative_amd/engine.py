@@ -70,12 +70,24 @@ class Generator:
         check(lib.qgx_generator_info(self._h, C.byref(p), C.byref(e), C.byref(f), mx))
         return dict(precision=p.value, ascale_log2=e.value, fold=f.value, layer_absmax=list(mx))
 
-    def wino_info(self):
-        """the 5x5 layer's 1-D Winograd form (64 x 64): dict(enabled, chosen_by_calibration, calibration_error) — it is the
-        default only if its outputs on calibration inputs stayed within 1e-5 of the exact-f32 kernels' at construction"""
+    def wino_info(self, N=None):
+        """the 5x5 layer's 1-D Winograd form: dict(enabled, chosen_by_calibration, calibration_error, N) — at a grid size it
+        is the default only if its outputs on calibration inputs OF THAT SIZE stayed within 1e-5 of the exact-f32 kernels' at
+        construction (measured at each of 32, 48, 64, 96, 128).  N = None: the 64 x 64 entry"""
         en, au, err = C.c_int(0), C.c_int(0), C.c_float(0)
-        check(lib.qgx_generator_wino_info(self._h, C.byref(en), C.byref(au), C.byref(err)))
-        return dict(enabled=bool(en.value), chosen_by_calibration=bool(au.value), calibration_error=err.value)
+        if N is None:
+            check(lib.qgx_generator_wino_info(self._h, C.byref(en), C.byref(au), C.byref(err)))
+        else:
+            check(lib.qgx_generator_wino_info_n(self._h, int(N), C.byref(en), C.byref(au), C.byref(err)))
+        return dict(enabled=bool(en.value), chosen_by_calibration=bool(au.value), calibration_error=err.value, N=64 if N is None else int(N))
+
+    LAYER2_KERNELS = ('exact-f32', '25-tap', '25-tap split-K', 'winograd', 'winograd, transform under the MFMAs')
+
+    def layer2_kernel(self, B, N, inet=0):
+        """index into LAYER2_KERNELS of the kernel the 5x5 layer takes for B members at N x N under the options in force"""
+        k = C.c_int(0)
+        check(lib.qgx_generator_layer2_kernel(self._h, int(inet), int(B), int(N), C.byref(k)))
+        return k.value
 
     def range_read(self):
         """Synchronise and return (flags, input_absmax) of the range guard since the last read; clears them.
@@ -97,7 +109,9 @@ class Generator:
 
     def _guarded(self, launch):
         """Run `launch()`; if the 16-bit window was left, switch this generator to the exact-f32 kernels for good
-        and run it again, so that the caller always receives a float32-class result."""
+        and run it again.  What the caller receives is inside the 2e-5 (of max|y|) the golden vectors are held to: float32
+        error class (1-2e-6) from the 25-tap and exact-f32 kernels, 3-9e-6 where the Winograd form of the 5x5 layer was
+        admitted by its calibration at this grid size (bound 1e-5, `wino_info(N)`; `set_option('wino', 0)` turns it off)."""
         out = launch()
         if self.check_range:
             why = self.range_ok()

@@ -22,11 +22,13 @@ def shard_members(total_members, rank, world):
     return first, n_local
 
 
-def init_process_group(backend=None):
-    """torch.distributed bootstrap from the torchrun environment (127.0.0.1 rendezvous)."""
+def init_process_group(backend=None, single_rank=False):
+    """torch.distributed bootstrap from the torchrun environment (127.0.0.1 rendezvous).  A one-rank job needs no
+    process group (-> None) unless ``single_rank``: then the group is created all the same, so that the collective
+    path — RCCL on a one-GPU box — can be exercised (tests/test_gpu_facade.py)."""
     import torch.distributed as dist
     rank, world = rank_world()
-    if world == 1:
+    if world == 1 and not single_rank:
         return None
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
@@ -47,6 +49,6 @@ def ensemble_mean(local_sum, local_count, group=None):
     import torch.distributed as dist
     buf = torch.cat([local_sum.reshape(-1).to(torch.float64),
                      torch.tensor([float(local_count)], dtype=torch.float64, device=local_sum.device)])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():          # (a one-rank group too: the same code path at every job size)
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return (buf[:-1] / buf[-1]).reshape(local_sum.shape)

@@ -180,7 +180,7 @@ def forecast_statistics(ds, n_local, xr=None, group=None):
     xr = xr or dataset_backend()
     names = ('q', 'u', 'v', 'psi')
     out = xr.Dataset(attrs=dict(ds.attrs))
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = dist.is_available() and dist.is_initialized()      # (a one-rank group takes the collective path as well)
     if not multi:
         for var in names:
             out[var] = ds[var].isel(run=0)
@@ -224,9 +224,10 @@ def run_forecast(pyqg_params, parameterization, q_init, n_ens, operator=None, sa
         q_init = op(q_init, nx)
     first, n_local = 0, n_ens
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # checked on EVERY rank before anything is sharded: a rank that raised alone would leave the others in the all-reduce
+        if n_ens < dist.get_world_size():
+            raise ValueError(f'n_ens={n_ens} leaves some of the {dist.get_world_size()} ranks without a member')
         first, n_local = parallel.shard_members(n_ens, dist.get_rank(), dist.get_world_size())
-        if n_local < 1:
-            raise ValueError(f'n_ens={n_ens} leaves rank {dist.get_rank()} without a member')
     ds = run_simulation(pyqg_params, parameterization, q_init=q_init, sampling_freq=sampling_freq,
                         n_members=n_local, device=device, seed=seed, member_offset=first)[['q', 'u', 'v', 'psi']]
     if n_local == 1:

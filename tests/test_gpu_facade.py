@@ -389,6 +389,54 @@ def test_bench_two_rank_rehearsal_over_gloo(mode):
     assert 'steady' not in out and 'config4' not in out                                      # auxiliary legs: one rank only
 
 
+_RCCL_CHILD = r'''
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from pyqg_generative_amd import parallel
+from pyqg_generative_amd.tools.simulate import forecast_statistics, dataset_backend
+import torch.distributed as dist
+d = parallel.init_process_group('nccl', single_rank=True)
+assert d is not None and dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+rs = np.random.RandomState(3)
+spec = torch.as_tensor(rs.rand(5, 2, 64, 33), device='cuda')              # five members' spectra on the device
+mean = parallel.ensemble_mean(spec.sum(0), 5)                             # all-reduce of the partial sum: on RCCL
+torch.cuda.synchronize()
+ok_mean = bool(torch.allclose(mean, spec.mean(0), rtol=1e-14, atol=0) and mean.is_cuda)
+xr = dataset_backend()
+f = rs.randn(3, 2, 2, 16, 16)
+ds = xr.Dataset({v: (['run', 'time', 'lev', 'y', 'x'], f * (i + 1)) for i, v in enumerate(('q', 'u', 'v', 'psi'))})
+out = forecast_statistics(ds, 3, xr)                                       # one all-reduce + one broadcast: on RCCL
+ok_fc = all(np.allclose(np.asarray(out[v + '_mean'].values), (f * (i + 1)).mean(0), rtol=1e-13, atol=1e-300) and
+            np.array_equal(np.asarray(out[v].values), (f * (i + 1))[0]) for i, v in enumerate(('q', 'u', 'v', 'psi')))
+dist.barrier()
+dist.destroy_process_group()
+print(json.dumps(dict(ok_mean=ok_mean, ok_forecast=ok_fc, nccl=list(torch.cuda.nccl.version()))))
+'''
+
+
+def test_the_collective_path_executes_on_rccl_in_a_one_rank_group(tmp_path):
+    """No multi-GPU node has been available to this build (DESIGN section 6), and a one-GPU box cannot hold two RCCL
+    ranks.  What it CAN show: in a FRESH child process (nothing that touched the GPU is re-executed) `nccl` initialises
+    with `device_id`, RCCL loads, and the path's collectives — `parallel.ensemble_mean` (all-reduce of partial spectral sums,
+    reference: ds[spec].mean('run'), comparison_tools.py:167-168) and `forecast_statistics` (all-reduce + broadcast,
+    simulate.py:284-290) — execute on device tensors in a group of one rank and return the local result."""
+    import subprocess, sys, socket
+    root = os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0]
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / 'rccl_child.py'
+    script.write_text(_RCCL_CHILD)
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    print(out)
+    assert out['ok_mean'] and out['ok_forecast']
+
+
 def test_offline_predict_returns_the_reference_dataset_layout(tmp_path):
     """predict(ds, M) (cgan_regression.py:173-189, mean_var_model.py:117-135): one sample, mean and variance of the
     forcing for every snapshot of a dataset with q (run, time, lev, y, x)."""

@@ -186,6 +186,8 @@ def test_a_flagged_run_is_undone_and_replayed_on_the_three_launch_path():
         pytest.skip(out['skip'])
     assert out['state_before'] == 1 and out['state_after'] == -1 and out['tc'] == 12
     assert out['err_qh'] < 1e-13 and out['err_dq'] < 1e-13 and out['err_dqpp'] < 1e-13
+    # the same, settled by a read on ANOTHER stream than the run was launched on: the copy waits for the replayed steps
+    assert out['state_after_2'] == -1 and out['err_qh_other_stream'] < 1e-13
     # the product library refuses the hook
     import pyqg_generative_amd._lib as L
     e = _engine(1, dt=3600.)
@@ -216,6 +218,23 @@ def _fault_child():
     out = dict(state_before=before, state_after=e.run_kernel_state, tc=e.tc)
     for key, f in (('err_qh', L.F_QH), ('err_dq', L.F_DQHDT), ('err_dqpp', L.F_DQHDT_PP)):
         out[key] = float(_rel(e.get(f).cpu().numpy(), ref.get(f).cpu().numpy()))
+    # a second model: the flagged run is settled by qgx_get on a side stream (team_settle replays on the run's stream and
+    # orders the caller's stream behind the replay)
+    import torch
+    e2, ref2 = _engine(B, dt=3600.), _engine(B, dt=3600.)
+    ref2.set_option('team', 0)
+    for x in (e2, ref2):
+        x.set_q(q0)
+        x.step(3, refresh_diag=False)
+    e2.set_option('team_fault', 1)
+    e2.step(6, refresh_diag=False)
+    ref2.step(6, refresh_diag=False)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        got = e2.get(L.F_QH)
+        side.synchronize()
+    out['state_after_2'] = e2.run_kernel_state
+    out['err_qh_other_stream'] = float(_rel(got.cpu().numpy(), ref2.get(L.F_QH).cpu().numpy()))
     print(json.dumps(out))
 
 

@@ -323,3 +323,82 @@ def test_an_ensemble_stepped_as_two_halves_on_two_streams_is_the_same_ensemble()
         assert e.step_streams(gen) == (2 if N == 96 else 1) and e.step_streams(None) == 1
         e.close()
         gen.close()
+
+
+def test_a_failing_half_of_a_two_stream_step_joins_the_streams_and_marks_the_model_invalid():
+    """qgx_step's error paths (model.hip): whatever fails after the fork, the caller's stream is joined with both internal
+    streams, and a step that failed after one half advanced leaves the handle INVALID — later calls fail loudly instead of
+    stepping from halves that stand at different steps.  The failure is injected by a hook of the A/B library (option
+    'step_fault': that half refuses its second chunk of steps), hence the child process on libqgx_ab.so."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ab = os.path.join(root, 'pyqg_generative_amd', 'libqgx_ab.so')
+    if not os.path.exists(ab):
+        pytest.skip('libqgx_ab.so is not built (make -C pyqg_generative_amd/csrc ab)')
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), 'stepfault-child'], env=dict(os.environ, QGX_LIB=ab),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print(out)
+    for half in ('1', '2'):
+        o = out[half]
+        assert o['step_raised'] and 'injected failure' in o['step_error']
+        assert o['next_step_raised'] and 'model state is invalid' in o['next_error'] and 'halves are at steps' in o['next_error']
+        assert o['get_raised'] and o['stream_usable'] and o['fresh_model_ok']
+    # the product library refuses the hook
+    import pyqg_generative_amd as qa
+    import pyqg_generative_amd._lib as L
+    e = qa.EnsembleEngine(nx=96, n_members=16, dt=3600.)
+    with pytest.raises(L.QgxError, match='A/B library only'):
+        e.set_option('step_fault', 1)
+    e.close()
+
+
+def _stepfault_child():
+    import json
+    import torch
+    import pyqg_generative_amd as qa
+    from pyqg_generative_amd import _lib as L, weights
+    nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, 'weights_vae.npz'), 'vae')
+    gen = qa.Generator('vae', nets, xs, ys)
+    N, B = 96, 32
+    q0 = np.random.RandomState(5).randn(B, 2, N, N) * 1e-6
+    kw = dict(generator=gen, sampling='AR1', nsteps_decor=1, seed=3)
+    out = {}
+    for half in (1, 2):
+        e = qa.EnsembleEngine(nx=N, n_members=B, dt=3600.)
+        assert e.step_streams(gen) == 2
+        e.set_q(q0)
+        e.step(3, **kw)
+        e.set_option('step_fault', half)
+        o = dict(step_raised=False, next_step_raised=False, get_raised=False)
+        try:
+            e.step(20, **kw)                        # three chunks of 8: the second chunk of that half is refused
+        except L.QgxError as ex:
+            o['step_raised'], o['step_error'] = True, str(ex)
+        e.set_option('step_fault', 0)
+        try:
+            e.step(1, **kw)
+        except L.QgxError as ex:
+            o['next_step_raised'], o['next_error'] = True, str(ex)
+        try:
+            e.get(L.F_QH)
+        except L.QgxError:
+            o['get_raised'] = True
+        # the caller's stream was joined: it is usable and ordered
+        t = torch.ones(1024, device='cuda')
+        torch.cuda.synchronize()
+        o['stream_usable'] = bool((t + 1).sum().item() == 2048)
+        e.close()
+        # a fresh handle is not affected
+        f = qa.EnsembleEngine(nx=N, n_members=B, dt=3600.)
+        f.set_q(q0)
+        f.step(9, **kw)
+        o['fresh_model_ok'] = bool(f.tc == 9 and np.isfinite(f.get(L.F_QH).cpu().numpy()).all())
+        f.close()
+        out[str(half)] = o
+    print(json.dumps(out))
+
+
+if __name__ == '__main__' and len(__import__('sys').argv) > 1 and __import__('sys').argv[1] == 'stepfault-child':
+    _stepfault_child()

@@ -173,6 +173,41 @@ def test_generator_matches_reference_golden(kind, N):
     assert np.abs(S.mean(axis=(1, 2))).max() < 1e-14 * scale.max() * N * N
 
 
+@pytest.mark.parametrize('kind', ['gan', 'vae', 'gz'])
+@pytest.mark.parametrize('N', [48, 64, 96])
+def test_generator_matches_reference_golden_on_the_ensemble_kernels(kind, N):
+    """The same reference-generated vectors on the kernels an ENSEMBLE takes by default (the golden test above runs one
+    member, i.e. the split-K 25-tap kernels): the golden member sits at three positions of a 40-member ensemble padded
+    with other fields, so the 5x5 layer runs as the 1-D Winograd kernel wherever calibration admitted it at this size
+    (k_convw2 / k_convw), the 3x3 layers as the fused pairs.  Same 2e-5 tolerance as the single member
+    (parameterization.py:23-34, cgan_regression.py:157-162)."""
+    g = golden('generator.npz')
+    gen = _gpu_generator(kind)
+    B = 40
+    rs = np.random.RandomState(11)
+    q0 = g[f'{kind}_{N}_q'].astype('float64')
+    z0 = g[f'{kind}_{N}_z'].reshape(2, N, N)
+    q = rs.randn(B, 2, N, N) * np.array([7.8e-6, 1.05e-6]).reshape(1, 2, 1, 1)
+    z = rs.randn(B, 2, N, N).astype(z0.dtype)
+    where = (0, 17, B - 1)
+    for b in where:
+        q[b], z[b] = q0, z0
+    qd, zd = torch.as_tensor(q).cuda().contiguous(), torch.as_tensor(z).cuda().contiguous()
+    k = gen.layer2_kernel(B, N)
+    info = gen.wino_info(N)
+    assert (k >= 3) == info['enabled'], (k, info)
+    S = gen.forward(qd, zd, demean=True).cpu().numpy()
+    Sraw = gen.forward(qd, zd, demean=False).cpu().numpy()
+    ref, ref_raw = g[f'{kind}_{N}_S'], g[f'{kind}_{N}_Sraw']
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    errs = [(np.abs(Sraw[b] - ref_raw) / scale).max() for b in where]
+    print(f'\n{kind} {N}x{N}, 40 members: layer 2 = {gen.LAYER2_KERNELS[k]} {info}; max error / max|S| {max(errs):.2e}')
+    for b in where:
+        assert (np.abs(Sraw[b] - ref_raw) / scale).max() < 2e-5
+        assert (np.abs(S[b] - ref) / scale).max() < 2e-5
+    assert np.array_equal(Sraw[where[0]], Sraw[where[1]]) and np.array_equal(Sraw[where[0]], Sraw[where[2]])
+
+
 def test_cnn_layers_match_reference_batched():
     """Batched raw CNN forward (B=5, N=32) against the oracle's torch-CPU restatement."""
     gen = _gpu_generator('gan')

@@ -108,7 +108,7 @@ def test_winograd_5x5_layer_is_float32_class(kind, fold):
     gen = _gpu_generator(kind)
     info = gen.wino_info()
     print(kind, info)
-    assert info['calibration_error'] > 0 and info['enabled'] == (info['calibration_error'] <= 1e-5)
+    assert info['N'] == 64 and info['calibration_error'] > 0 and info['enabled'] == (info['calibration_error'] <= 1e-5)
     nets = _oracle_nets(kind)
     N, B = 64, 8
     rs = np.random.RandomState(11)
@@ -144,6 +144,64 @@ def test_winograd_5x5_layer_is_float32_class(kind, fold):
         assert (np.abs(S - S_ref) / np.abs(S_ref).max(axis=(1, 2), keepdims=True)).max() < 2e-5
 
 
+@pytest.mark.parametrize('kind', ['gan', 'vae', 'gz'])
+@pytest.mark.parametrize('N,B', [(32, 32), (48, 8), (96, 4), (128, 2)])
+def test_winograd_5x5_layer_at_the_other_grid_sizes(kind, N, B):
+    """the Winograd layer's other tile shapes (16 x 32 / 8 x 32 tiles at 32 x 32, 16 x 16 at 48 x 48, 12 / 16 x 32 at 96 x 96, 8 / 4 x
+    64 at 128 x 128) against the float64 truth of the same float32 parameters, and the admission made AT that size: calibration
+    measured each size on inputs of that size (`wino_info(N)`), the default path obeys it, and forced on the form stays inside
+    the golden-vector tolerance for the shipped nets"""
+    gen = _gpu_generator(kind)
+    info = gen.wino_info(N)
+    print(kind, info)
+    assert info['N'] == N and info['calibration_error'] > 0 and info['enabled'] == (info['calibration_error'] <= 1e-5)
+    nets = _oracle_nets(kind)
+    rs = np.random.RandomState(5 + N)
+    x = rs.randn(B, nets[0].n_in, N, N).astype('float32')
+    x[:, :2] *= 1.5
+    xd = torch.as_tensor(x, device='cuda')
+    nb = min(B, 2)
+    for inet, w in enumerate(nets):
+        truth = gen_ref.cnn_forward(w, x[:nb], dtype='float64')
+        err_ref = _maxrel(gen_ref.cnn_forward(w, x[:nb]), truth)
+        errs = {}
+        for name, opts in (('25-tap', dict(wino=0)), ('winograd', dict(wino=1, wino_min_tiles=1)), ('default', dict(wino=2, wino_min_tiles=1))):
+            for k, v in opts.items():
+                gen.set_option(k, v)
+            gen.set_option('part_max_tiles', 0)
+            errs[name] = _maxrel(gen.cnn_forward(xd, inet).cpu().numpy()[:nb], truth)
+            kk = gen.layer2_kernel(B, N, inet)
+            assert (kk >= 3) == (name == 'winograd' or (name == 'default' and info['enabled'])), (name, kk)
+        print(f'\n{kind} net{inet} {N}x{N}: vs float64 truth: torch-f32 {err_ref:.2e}, f16x3 25-tap {errs["25-tap"]:.2e}, '
+              f'winograd {errs["winograd"]:.2e}, default {errs["default"]:.2e}')
+        assert errs['25-tap'] < 4 * err_ref + 1e-7
+        assert errs['winograd'] < 2e-5 and errs['default'] < 2e-5
+        assert gen.range_ok() is None
+
+
+def test_winograd_layer_with_the_transform_under_the_mfmas_is_bit_identical():
+    """k_convw2 (conv_wino2.hpp: the eight positions as two teams of waves in ping-pong, the input transform under the MFMAs)
+    against k_convw (option wino2 = 0): the same arithmetic in the same order — bit-identical outputs at the sizes it is
+    built for, full tiles and a ragged tile count"""
+    gen = _gpu_generator('gan')
+    gen.set_option('wino', 1)
+    gen.set_option('wino_min_tiles', 1)
+    for N, B, opts in ((64, 128, {}), (64, 37, dict(wino_rows64=8)), (96, 32, dict(wino_rows96=12)), (96, 11, dict(wino_rows96=12))):
+        for k, v in opts.items():
+            gen.set_option(k, v)
+        rs = np.random.RandomState(N + B)
+        xd = torch.as_tensor(rs.randn(B, 4, N, N).astype('float32'), device='cuda')
+        out = {}
+        for w2 in (0, 1):
+            gen.set_option('wino2', w2)
+            assert gen.layer2_kernel(B, N) == (4 if w2 else 3), (N, B, w2, gen.layer2_kernel(B, N))
+            out[w2] = gen.cnn_forward(xd).clone()
+        assert torch.equal(out[0], out[1]), (N, B)
+        gen.set_option('wino_rows64', 0)
+        gen.set_option('wino_rows96', 0)
+    assert gen.range_ok() is None
+
+
 VARIANTS = [                                     # selectable variants of the product library
     dict(part_max_tiles=100000),                 # split-K on the wide layers (single-member path)
     dict(pair=0, fuse=0),                        # k_convh2 without the line-pair fetch
@@ -154,6 +212,7 @@ VARIANTS = [                                     # selectable variants of the pr
     dict(first_h=0),                             # exact-f32 first layer writing the 16-bit layout
     dict(fold=0),                                # layer 1's BatchNorm applied in its epilogue instead of folded into layer 2
     dict(wino=0),                                # 5x5 layer as the 25-tap implicit GEMM instead of the 1-D Winograd form
+    dict(wino2=0),                               # the Winograd layer as k_convw instead of k_convw2 (transform under the MFMAs)
     dict(wino_min_tiles=1),                      # ... the Winograd form at every ensemble size (64 x 64)
     dict(wino_min_tiles=1, fold=0),
     dict(wino_rows64=4), dict(wino_rows64=8),    # tile shapes the launchers otherwise choose by tile-count quantisation
@@ -171,7 +230,7 @@ AB_VARIANTS = [                                  # kernels of the A/B library on
     dict(h4=1), dict(h4=2),                      # 5x5 layer with full-line patch chunks (k_convh4)
 ]
 DEFAULTS = dict(fuse=3, pair=1, first_h=1, member_chunk=0, part_max_tiles=0, fold=1, h2_w8=3, ascale_log2=0, h2_x96=1, h2_w8_min96=1024,
-                wino=1, wino_min_tiles=48, wino_rows64=0, wino_rows96=0, h2_rows96=0, fuse96=2, small_tiles=1)
+                wino=2, wino2=1, wino_min_tiles=48, wino_rows64=0, wino_rows96=0, h2_rows96=0, fuse96=2, small_tiles=1)
 AB_DEFAULTS = dict(DEFAULTS, h2=3, half_nw=8, res=1, h3=0, h4=0)
 
 
@@ -210,6 +269,7 @@ def test_optional_kernel_variants_agree(N, B):
 
 @pytest.mark.parametrize('N,B,opts', [(64, 16, dict(wino_rows64=[4, 8])), (64, 48, dict(wino_rows64=[4, 8])),
                                       (96, 32, dict(wino_rows96=[12, 16], h2_rows96=[12, 16])), (96, 12, dict(wino_rows96=[12, 16], h2_rows96=[12, 16])),
+                                      (32, 96, dict(wino_rows64=[4, 8])), (128, 2, dict(wino_rows64=[4, 8])), (128, 12, dict(wino_rows64=[4, 8])),
                                       (64, 1, dict(small_tiles=[0, 1])), (64, 4, dict(small_tiles=[0, 1]))])
 def test_tile_shapes_do_not_change_the_result(N, B, opts):
     """the launchers choose tile shapes per launch by tile-count quantisation (256 persistent workgroups take ceil(tiles / 256)
@@ -220,12 +280,22 @@ def test_tile_shapes_do_not_change_the_result(N, B, opts):
     gen.check_range = False
     rs = np.random.RandomState(N + 31 * B)
     x = torch.as_tensor(rs.randn(B, 4, N, N).astype('float32'), device='cuda')
+    if N in (32, 128):
+        # shapes the launchers pick by themselves only at these ensemble sizes (k_convw<32,32,16> beyond 64 members, k_convw<128,64,4> for
+        # 4 members or fewer, or 12): with the Winograd form forced on, and against the 25-tap form at the golden-vector tolerance
+        gen.set_option('wino', 1)
+        gen.set_option('wino_min_tiles', 1)
     ref = gen.cnn_forward(x).cpu().numpy()                                   # the automatic choice
     for name, values in opts.items():
         for v in values:
             gen.set_option(name, v)
             assert np.array_equal(gen.cnn_forward(x).cpu().numpy(), ref), (name, v)
         gen.set_option(name, 0 if name != 'small_tiles' else 1)
+    if N in (32, 128):
+        assert gen.layer2_kernel(B, N) == 3
+        gen.set_option('wino', 0)
+        y25 = gen.cnn_forward(x).cpu().numpy()
+        assert np.abs(y25 - ref).max() < 2e-5 * np.abs(y25).max()
     gen.close()
 
 
