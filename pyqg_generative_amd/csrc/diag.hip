@@ -25,6 +25,10 @@ int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh
                          double weight, const double *q, const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st);
 
 
+bool small_diag_increment_reg_ok(const SpecDev &d);
+int small_diag_increment_reg(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, const double *S, double weight, const double *q,
+                             const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st);
+
 int small_diag_transforms_wide(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
                                double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, double2 *S6, double2 *S7, const double *S,
                                double weight, const double *q, hipStream_t st);
@@ -141,6 +145,15 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
                            S ? (const double2 *)Sh : (const double2 *)nullptr, (const double2 *)S6, (const double2 *)S7, dq_p, dq_pp, a);
         QGX_HIP(hipGetLastError());
         m->uv_stale = false;
+        m->dg_count += 1;
+        return QGX_OK;
+    }
+    if (m->small && m->opts.diag_fused && m->opts.diag_reg && small_diag_increment_reg_ok(d)) {
+        // grids up to 64 x 64: the same in ONE kernel whose work fields stay in registers (k_diag_small_reg: a quarter of the
+        // bytes); it stores ph but no u, v — they are marked stale and inverted on demand
+        rc = small_diag_increment_reg(d, c, qh, m->ph, S, weight, m->q, dq_p, dq_pp, a, st);
+        if (rc) return rc;
+        m->uv_stale = true;
         m->dg_count += 1;
         return QGX_OK;
     }

@@ -5,26 +5,45 @@
 
 namespace qgx {
 
+// PARTS: which diagnostics this call updates (k_diag_small_reg accumulates the ones fed by a product transform as soon as that
+// transform is in LDS: the expressions are these very ones, so the accumulators come out bit-identical): 1 = APEflux (needs the
+// spectra A3, B3), 2 = KEflux (A4, B4, A5, B5), 4 = all the others; 7 = everything
+// JPRE: A4 and A6 carry the layer-1 Jacobians (j1x, j1y) and (g1x, g1y) already formed by diag_jacobian() — the same two
+// expressions — instead of the spectra they are formed from (B4, B6 unused): half the registers to hold across a transform
+// (explicit fused multiply-adds: written as kx A + ly B it is the compiler's choice which of the two products it fuses, and it
+//  chooses differently in different kernels — a last-bit difference between the variants of the increment)
+__device__ __forceinline__ double2 diag_jacobian(double kx, double ly, double2 A, double2 B) {
+    return make_double2(-__builtin_fma(kx, A.y, ly * B.y), __builtin_fma(kx, A.x, ly * B.x));
+}
+__device__ __forceinline__ double diag_dot(double2 a, double bx, double by) { return __builtin_fma(a.x, bx, a.y * by); }
+template <int PARTS = 7, bool JPRE = false>
 __device__ __forceinline__ void diag_accumulate_elem(const SpecDev &d, const DiagConst &c, const DiagAcc &a, int idx, int i, int j,
                                                      size_t o, size_t o2, int sz, double2 q1, double2 q2, double2 p1, double2 p2,
                                                      double2 A3, double2 B3, double2 A4, double2 B4, double2 A5, double2 B5,
                                                      bool has_S, double2 s1, double2 s2, double2 A6, double2 B6, double2 A7,
                                                      double2 B7, double2 hp1, double2 hp2, double2 hpp1, double2 hpp2) {
     const double kx = d.kk[i], ly = d.ll[j], wv2 = d.wv2[idx];
-    a.KEspec[o] += wv2 * (p1.x * p1.x + p1.y * p1.y) * c.invM2;
-    a.KEspec[o + sz] += wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
-    a.Ensspec[o] += (q1.x * q1.x + q1.y * q1.y) * c.invM2;
-    a.Ensspec[o + sz] += (q2.x * q2.x + q2.y * q2.y) * c.invM2;
-    const double ex = c.del1 * q1.x + c.del2 * q2.x, ey = c.del1 * q1.y + c.del2 * q2.y;
-    a.entspec[o2] += (ex * ex + ey * ey) * c.invM2;
-    // Jptpc = -(ik A + il B), (A,B) = S3
-    const double jx = (kx * A3.y + ly * B3.y), jy = -(kx * A3.x + ly * B3.x);
     const double dpx = p1.x - p2.x, dpy = p1.y - p2.y;
-    a.APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * jx + dpy * jy) * c.invM2;
-    // Jpxi_k = ik A + il B
-    const double j1x = -(kx * A4.y + ly * B4.y), j1y = (kx * A4.x + ly * B4.x);
-    const double j2x = -(kx * A5.y + ly * B5.y), j2y = (kx * A5.x + ly * B5.x);
-    a.KEflux[o2] += (c.del1 * (p1.x * j1x + p1.y * j1y) + c.del2 * (p2.x * j2x + p2.y * j2y)) * c.invM2;
+    if (PARTS & 4) {
+        a.KEspec[o] += wv2 * (p1.x * p1.x + p1.y * p1.y) * c.invM2;
+        a.KEspec[o + sz] += wv2 * (p2.x * p2.x + p2.y * p2.y) * c.invM2;
+        a.Ensspec[o] += (q1.x * q1.x + q1.y * q1.y) * c.invM2;
+        a.Ensspec[o + sz] += (q2.x * q2.x + q2.y * q2.y) * c.invM2;
+        const double ex = c.del1 * q1.x + c.del2 * q2.x, ey = c.del1 * q1.y + c.del2 * q2.y;
+        a.entspec[o2] += (ex * ex + ey * ey) * c.invM2;
+    }
+    if (PARTS & 1) {
+        // Jptpc = -(ik A + il B), (A,B) = S3
+        const double jx = (kx * A3.y + ly * B3.y), jy = -(kx * A3.x + ly * B3.x);
+        a.APEflux[o2] += c.rdm2 * c.del1 * c.del2 * (dpx * jx + dpy * jy) * c.invM2;
+    }
+    if (PARTS & 2) {
+        // Jpxi_k = ik A + il B
+        const double2 j1 = JPRE ? A4 : diag_jacobian(kx, ly, A4, B4), j2 = diag_jacobian(kx, ly, A5, B5);
+        const double j1x = j1.x, j1y = j1.y, j2x = j2.x, j2y = j2.y;
+        a.KEflux[o2] += __builtin_fma(c.del1, diag_dot(p1, j1x, j1y), c.del2 * diag_dot(p2, j2x, j2y)) * c.invM2;
+    }
+    if (!(PARTS & 4)) return;
     // APEgenspec = U rd^-2 del1 del2 Re[ i k (del1 p1 + del2 p2) conj(p1 - p2) ]
     const double bx = c.del1 * p1.x + c.del2 * p2.x, by = c.del1 * p1.y + c.del2 * p2.y;
     // i k (bx + i by) = (-k by, k bx); Re[(.)*conj(dp)] = (-k by) dpx + (k bx) dpy
@@ -49,9 +68,9 @@ __device__ __forceinline__ void diag_accumulate_elem(const SpecDev &d, const Dia
     // qg_model.py::_initialize_model_diagnostics): every term is Re[sum_k Hk/H conj(qh_k) X_k] / M^2 for one term X_k of
     // the PV tendency, so that they close the budget of sum_k Hk/H |qh_k|^2 / 2 wavenumber by wavenumber.
     // Jq_k = ik A + il B, (A, B) = transforms of (u_k q_k, v_k q_k) with the PERTURBATION velocities (model.py::_advect)
-    const double g1x = -(kx * A6.y + ly * B6.y), g1y = (kx * A6.x + ly * B6.x);
-    const double g2x = -(kx * A7.y + ly * B7.y), g2y = (kx * A7.x + ly * B7.x);
-    a.ENSflux[o2] += -(c.H0 * (q1.x * g1x + q1.y * g1y) + c.H1 * (q2.x * g2x + q2.y * g2y)) * c.invM2;
+    const double2 g1 = JPRE ? A6 : diag_jacobian(kx, ly, A6, B6), g2 = diag_jacobian(kx, ly, A7, B7);
+    const double g1x = g1.x, g1y = g1.y, g2x = g2.x, g2y = g2.y;
+    a.ENSflux[o2] += -__builtin_fma(c.H0, diag_dot(q1, g1x, g1y), c.H1 * diag_dot(q2, g2x, g2y)) * c.invM2;
     // -Re[conj(qh_k) ik Qy_k ph_k] = -k Qy_k (q.y p.x - q.x p.y)
     a.ENSgenspec[o2] += -kx * (c.H0 * d.Qy[0] * (q1.y * p1.x - q1.x * p1.y) + c.H1 * d.Qy[1] * (q2.y * p2.x - q2.x * p2.y)) * c.invM2;
     a.ENSfrictionspec[o2] += c.rek * c.H1 * wv2 * (q2.x * p2.x + q2.y * p2.y) * c.invM2;

@@ -485,6 +485,218 @@ __global__ void k_diag_small(SpecDev d, DiagConst c, const double2 *qh, double2 
     }
 }
 
+// ------------------------------------------------------------------ the same increment with its work fields in registers
+// k_diag_small moves 3.6 MB per member (468 MB per 128-member increment, PMC) where the increment's own bytes are 0.94 MB
+// (qh, q, S, the two older tendencies, sixteen accumulators read and written once): every real-space field (u, v, p, xi: 260
+// KB) goes to HBM and comes back two or three times, the six product spectra (810 KB) go out and come back for the
+// accumulation.  Here a thread keeps the pixels it owns of (u_1, v_1, u_2, v_2) in registers for the whole kernel, forms each
+// product pair straight into the LDS field it has just read, and accumulates as soon as a transform is in LDS: APEflux
+// after the (ub ptpc, vb ptpc) transform, KEflux after the two (u_k xi_k, v_k xi_k) ones (J_1 held in registers), the rest
+// after the last transform (the forcing's and the layer-1 enstrophy flux's spectra held in registers).  Same device
+// functions, same expressions, same element -> thread map: the accumulators are BIT-identical to k_diag_small's.  It stores
+// ph but no u, v (the caller marks them stale: qgx_get inverts on demand).  Grids up to 64 x 64 (at 96 x 96 nine pixels per
+// thread do not fit the 128 registers of a 1024-thread workgroup).
+// LDS of k_diag_small_reg: the field + tables of small_lds_bytes(), then the forcing's two half spectra
+__host__ __device__ constexpr size_t diag_reg_side_offset(int N) {
+    return (((size_t)N * (N + 1) * sizeof(double2) + (size_t)((N + 3) & ~3) * sizeof(int) + (size_t)N * sizeof(double2)) + 15) & ~(size_t)15;
+}
+__host__ __device__ constexpr size_t diag_reg_lds_bytes(int N) { return diag_reg_side_offset(N) + (size_t)2 * N * (N / 2 + 1) * sizeof(double2); }
+template <int NN>
+__global__ __launch_bounds__(1024) void k_diag_small_reg(SpecDev d, DiagConst c, const double2 *qh, double2 *ph, const double *S, double weight,
+                                                         const double *q, const double2 *dq_p, const double2 *dq_pp, DiagAcc acc) {
+    double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
+    int *pos_lds;
+    Grid g = make_grid(d, Z, pos_lds);
+    g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1;
+    constexpr int N = NN, NK = NN / 2 + 1, LD = NN + 1, sz = N * NK, rz = N * N;
+    constexpr int NPX = (rz + 1023) / 1024, NSP = (sz + 1023) / 1024;
+    const int b = blockIdx.x;
+    const size_t so = (size_t)b * 2 * sz, ro = (size_t)b * 2 * rz;
+    const double2 *qh0 = qh + so, *qh1 = qh + so + sz;
+    double u1[NPX], v1[NPX], u2[NPX], v2[NPX];
+    __syncthreads();
+    // ---- _invert: (u_k + i v_k) of both layers into registers
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        build_uv(Z, g, d, k, qh0, qh1, ph + so + k * sz);
+        __syncthreads();
+        fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+#pragma unroll
+        for (int r = 0; r < NPX; ++r) {
+            const int idx = threadIdx.x + r * 1024;
+            if (idx < rz) {
+                const int y = idx / N, x = idx - y * N;
+                const double2 uv = Z[y * LD + x];
+                if (k == 0) { u1[r] = uv.x; v1[r] = uv.y; } else { u2[r] = uv.x; v2[r] = uv.y; }
+            }
+        }
+        __syncthreads();
+    }
+    // psi is stored once (68 KB per member) and read back wherever k_diag_small reads it: forming it anew from qh at each use
+    // would leave it to the compiler which of the two products of a0 q0 + a1 q1 it fuses — a last-bit difference between
+    // uses.  The packed spectrum of (f(psi_1) + i f(psi_2)); XIH: f = -K^2 psi (k_diag_small stages that through S3)
+    const double2 *ph0 = ph + so, *ph1 = ph + so + sz;
+    auto build_psi_pair = [&](bool XIH) {
+        for (int idx = threadIdx.x; idx < sz; idx += 1024) {
+            const int j = idx / NK, i = idx - j * NK;
+            double2 a = ph0[idx], bb = ph1[idx];
+            if (XIH) { const double w = -d.wv2[idx]; a = make_double2(w * a.x, w * a.y); bb = make_double2(w * bb.x, w * bb.y); }
+            if (i == 0 || 2 * i == N) {
+                const int idm = neg_mod(j, N) * NK + i;
+                double2 am = ph0[idm], bm = ph1[idm];
+                if (XIH) { const double w = -d.wv2[idm]; am = make_double2(w * am.x, w * am.y); bm = make_double2(w * bm.x, w * bm.y); }
+                a = make_double2(0.5 * (a.x + am.x), 0.5 * (a.y - am.y));
+                bb = make_double2(0.5 * (bb.x + bm.x), 0.5 * (bb.y - bm.y));
+            }
+            pack_store(Z, g, j, i, a, bb, d.invN2);
+        }
+    };
+    const double2 zero = make_double2(0., 0.);
+    // ---- p = irfft2(psi): ptpc = p_1 - p_2 is used once, by the first product pair, which goes straight back into the field
+    build_psi_pair(false);
+    __syncthreads();
+    fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+#pragma unroll
+    for (int r = 0; r < NPX; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < rz) {
+            const int y = idx / N, x = idx - y * N;
+            const double2 w = Z[y * LD + x];
+            const double ptpc = w.x - w.y;
+            const double ub = c.del1 * u1[r] + c.del2 * u2[r], vb = c.del1 * v1[r] + c.del2 * v2[r];
+            Z[y * LD + x] = make_double2(ub * ptpc, vb * ptpc);
+        }
+    }
+    __syncthreads();
+    fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < sz) {
+            const int j = idx / NK, i = idx - j * NK;
+            double2 A3, B3;
+            unpack_pair(Z, g, j, i, A3, B3);
+            const double2 p1 = ph0[idx], p2 = ph1[idx];
+            diag_accumulate_elem<1>(d, c, acc, idx, i, j, so + idx, (size_t)b * sz + idx, sz, zero, zero, p1, p2, A3, B3, zero, zero, zero, zero,
+                                    false, zero, zero, zero, zero, zero, zero, zero, zero, zero, zero);
+        }
+    }
+    __syncthreads();
+    // ---- xi = irfft2(-K^2 psi); (u_1 xi_1, v_1 xi_1) goes back into the field, xi_2 waits in registers
+    build_psi_pair(true);
+    __syncthreads();
+    fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    double xi2[NPX];
+#pragma unroll
+    for (int r = 0; r < NPX; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < rz) {
+            const int y = idx / N, x = idx - y * N;
+            const double2 w = Z[y * LD + x];
+            xi2[r] = w.y;
+            Z[y * LD + x] = make_double2(u1[r] * w.x, v1[r] * w.x);
+        }
+    }
+    __syncthreads();
+    fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    double2 J1[NSP];                                // Jacobian of layer 1, i k A + i l B (diag_acc.hpp), held for KEflux
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < sz) {
+            const int j = idx / NK, i = idx - j * NK;
+            double2 A4, B4;
+            unpack_pair(Z, g, j, i, A4, B4);
+            J1[r] = diag_jacobian(d.kk[i], d.ll[j], A4, B4);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NPX; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < rz) { const int y = idx / N, x = idx - y * N; Z[y * LD + x] = make_double2(u2[r] * xi2[r], v2[r] * xi2[r]); }
+    }
+    __syncthreads();
+    fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < sz) {
+            const int j = idx / NK, i = idx - j * NK;
+            double2 A5, B5;
+            unpack_pair(Z, g, j, i, A5, B5);
+            const double2 p1 = ph0[idx], p2 = ph1[idx];
+            diag_accumulate_elem<2, true>(d, c, acc, idx, i, j, so + idx, (size_t)b * sz + idx, sz, zero, zero, p1, p2, zero, zero, J1[r], zero, A5, B5,
+                                    false, zero, zero, zero, zero, zero, zero, zero, zero, zero, zero);
+        }
+    }
+    __syncthreads();
+    // ---- the forcing's spectrum (held in LDS behind the field and its tables: every thread re-reads what it wrote itself),
+    //      the enstrophy flux of layer 1 (held in registers), of layer 2, and everything else
+    double2 *SH = reinterpret_cast<double2 *>(qgx_smem + diag_reg_side_offset(NN));
+    if (S) {
+#pragma unroll
+        for (int r = 0; r < NPX; ++r) {
+            const int idx = threadIdx.x + r * 1024;
+            if (idx < rz) { const int y = idx / N, x = idx - y * N; Z[y * LD + x] = make_double2(weight * S[ro + idx], weight * S[ro + rz + idx]); }
+        }
+        __syncthreads();
+        fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+#pragma unroll
+        for (int r = 0; r < NSP; ++r) {
+            const int idx = threadIdx.x + r * 1024;
+            if (idx < sz) {
+                const int j = idx / NK, i = idx - j * NK;
+                double2 s1, s2;
+                unpack_pair(Z, g, j, i, s1, s2);
+                SH[idx] = s1; SH[sz + idx] = s2;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < NPX; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < rz) { const int y = idx / N, x = idx - y * N; const double q1 = q[ro + idx]; Z[y * LD + x] = make_double2(u1[r] * q1, v1[r] * q1); }
+    }
+    __syncthreads();
+    fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+    double2 G1[NSP];                                // Jacobian of (u_1 q_1, v_1 q_1), held for the enstrophy budget
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < sz) {
+            const int j = idx / NK, i = idx - j * NK;
+            double2 A6, B6;
+            unpack_pair(Z, g, j, i, A6, B6);
+            G1[r] = diag_jacobian(d.kk[i], d.ll[j], A6, B6);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < NPX; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < rz) { const int y = idx / N, x = idx - y * N; const double q2 = q[ro + rz + idx]; Z[y * LD + x] = make_double2(u2[r] * q2, v2[r] * q2); }
+    }
+    __syncthreads();
+    fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+#pragma unroll
+    for (int r = 0; r < NSP; ++r) {
+        const int idx = threadIdx.x + r * 1024;
+        if (idx < sz) {
+            const int j = idx / NK, i = idx - j * NK;
+            double2 A7, B7;
+            unpack_pair(Z, g, j, i, A7, B7);
+            const double2 q1 = qh0[idx], q2 = qh1[idx];
+            const double2 p1 = ph0[idx], p2 = ph1[idx];
+            const size_t o = so + idx;
+            diag_accumulate_elem<4, true>(d, c, acc, idx, i, j, o, (size_t)b * sz + idx, sz, q1, q2, p1, p2, zero, zero, zero, zero, zero, zero,
+                                          S != nullptr, S ? SH[idx] : zero, S ? SH[sz + idx] : zero, G1[r], zero, A7, B7, dq_p[o], dq_p[o + sz],
+                                          dq_pp[o], dq_pp[o + sz]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the same increment spread over several workgroups per member
 // One workgroup per member is a chain of ten dependent 2-D transforms on ONE CU (about 110 us for a single member, and half
 // of the CUs idle at 128).  The four inverse transforms depend on qh alone and the six forward transforms on their results
@@ -633,6 +845,8 @@ int small_prepare(const SpecDev &d) {
         QGX_HIP(hipFuncSetAttribute((const void *)k_qh_to_q_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_diag_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        if constexpr (NN == 32 || NN == 48 || NN == 64)
+            QGX_HIP(hipFuncSetAttribute((const void *)k_diag_small_reg<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_reg_lds_bytes(NN)));
         QGX_HIP(hipFuncSetAttribute((const void *)k_diag_inv_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_diag_fwd_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     })
@@ -666,6 +880,20 @@ int small_qh_to_q(const SpecDev &d, const ModelOpts &o, const double2 *qh, doubl
 }
 int small_invert(const SpecDev &d, const ModelOpts &o, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st) {
     QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_invert_small<NN>, dim3(d.B), dim3(small_threads(d, o)), small_lds_bytes(d), st, d, qh, ph, u, v))
+    QGX_HIP(hipGetLastError());
+    return QGX_OK;
+}
+// the one-workgroup-per-member increment with its work fields in registers (k_diag_small_reg): grids up to 64 x 64; stores no
+// ph, u, v.  -> false: no such kernel for this grid
+bool small_diag_increment_reg_ok(const SpecDev &d) { return d.N == 32 || d.N == 48 || d.N == 64; }
+int small_diag_increment_reg(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, const double *S, double weight, const double *q,
+                             const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st) {
+    switch (d.N) {
+        case 32: hipLaunchKernelGGL(k_diag_small_reg<32>, dim3(d.B), dim3(1024), diag_reg_lds_bytes(32), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
+        case 48: hipLaunchKernelGGL(k_diag_small_reg<48>, dim3(d.B), dim3(1024), diag_reg_lds_bytes(48), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
+        case 64: hipLaunchKernelGGL(k_diag_small_reg<64>, dim3(d.B), dim3(1024), diag_reg_lds_bytes(64), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
+        default: QGX_REQUIRE(false, "small_diag_increment_reg: no kernel for N = %d", d.N);
+    }
     QGX_HIP(hipGetLastError());
     return QGX_OK;
 }

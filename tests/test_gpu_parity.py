@@ -367,10 +367,11 @@ def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B
     gen = _gpu_generator(kind)
     res = []
     # default / separate generator kernels / one launch per transform / the increment's transforms as (member, transform)
-    # workgroups (three launches) / as ONE workgroup per member
-    for opt, val in ((None, 0), ('genfuse', 0), ('diag_fused', 0), ('diag_wide', 1), ('diag_wide', 0)):
+    # workgroups (three launches) / as ONE workgroup per member with its work fields in registers (k_diag_small_reg, grids up to
+    # 64 x 64: a quarter of the bytes) / ... with them in global memory (k_diag_small)
+    for opts in ({}, dict(genfuse=0), dict(diag_fused=0), dict(diag_wide=1), dict(diag_wide=0), dict(diag_wide=0, diag_reg=0)):
         e = _engine(N, B, dt=dt_for(N))
-        if opt:
+        for opt, val in opts.items():
             e.set_option(opt, val)
         e.set_q(q0)
         e.diag_config(0, 4)
