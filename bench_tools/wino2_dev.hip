@@ -150,6 +150,9 @@ int main(int argc, char **argv) {
         else if (exp == 7) run_shape<64, 64, 8, 7>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 8) run_shape<64, 64, 8, 8>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 9) run_shape<64, 64, 8, 9>(B, hin, dw, dbias, dscale, dshift, drange, 5);
+        else if (exp == 10) run_shape<64, 64, 8, 10>(B, hin, dw, dbias, dscale, dshift, drange, 5);
+        else if (exp == 11) run_shape<64, 64, 8, 11>(B, hin, dw, dbias, dscale, dshift, drange, 5);
+        else if (exp == 12) run_shape<64, 64, 8, 12>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else run_shape<64, 64, 8>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         std::vector<unsigned long long> st(16 * 512);
         CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));

@@ -1490,7 +1490,7 @@ static int launch_convh2_n(qgx_generator *g, int layer, const LayerHost &L, cons
     a.unscale = L.wh_unscale[1] / g->opt_ascale; a.ascale = OUTF32 ? 1.f : g->opt_ascale;
     a.range = g->range_dev; a.range_bit = 1u << layer;
     a.N = NN; a.R = R;
-    a.prio_alt = KS == 5 ? g->opt_prio_alt : 0;      // measured: -2 % on the 5x5 layer, nothing on the 3x3 layers
+    a.prio_alt = KS == 5 ? g->opt_prio_alt : (g->opt_prio_alt == 3 ? 3 : 0);      // measured: -2 % on the 5x5 layer, nothing on the 3x3 layers (3: by phase)
     a.stamps = layer == g->stamp_layer ? g->stamps : nullptr;
     const int total_tiles = B * (NN / R);
     int grid = lds * 2 <= 160 * 1024 ? 512 : 256;

@@ -630,6 +630,10 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
                             Pn[mt][j] = *reinterpret_cast<const h8 *>(lds0 + pbase[mt] + (ky_ * PW + kx_) * PSTR + j * 16); \
                 }
                 QGX_STAMP()
+                // prio_alt == 3 (two workgroups per CU): the MFMA loop at priority 0, everything else (prefetch stores, barriers,
+                // epilogue) at priority 3 — beside a partner wave whose next MFMA is always pending, vector instructions of equal
+                // priority issue every ~17 cycles instead of every ~5 (bench_tools/coissue.hip); the MFMA stream does not slow down
+                if (TWO && a.prio_alt == 3) __builtin_amdgcn_s_setprio(0);
                 QGX_H2_FRAGS(0)
 #pragma unroll
                 for (int tl = 0; tl < TPS; ++tl) {
@@ -677,6 +681,7 @@ __global__ __launch_bounds__(NW * 64, TWO ? 2 : 1) void k_convh2(ConvHArgs a, in
                 }
 #undef QGX_H2_FRAGS
                 QGX_STAMP()
+                if (TWO && a.prio_alt == 3) __builtin_amdgcn_s_setprio(3);
                 // ---- retire the prefetches
                 if constexpr (WDB) {
                     if (sl == NSL - 1) {

@@ -179,6 +179,16 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
 #endif
 #define QGX_TRANSFORM(TEAM, WSTEP)                                                                              \
     __builtin_amdgcn_s_setprio(QGX_W2_TPRIO);                                                                   \
+    if (EXP == 11) {                                                                                            \
+        float xf_[16];                                                                                          \
+        _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) xf_[k_] = 1.0f + 0.001f * (lane + k_);                \
+        _Pragma("unroll") for (int r_ = 0; r_ < 19; ++r_)                                                       \
+            _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(xf_[k_]) : "v"(0.999f), "v"(0.001f)); \
+        float sf_ = 0.f;                                                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) sf_ += xf_[k_];                                       \
+        if (sf_ == 12345.f) ep[0] = sf_;                                                                        \
+        QGX_W_LOAD(0, WSTEP)                                                                                    \
+    } else {                                                                                                    \
     QGX_OPAQUE_TID(tt_)                                                                                         \
     tt_ &= 255;                                                                                                 \
     const int it_t = tt_ % NQT, it_o = (tt_ / NQT) & 1, it_hf = (tt_ / (2 * NQT)) & 1, it_r0 = tt_ / (4 * NQT);  \
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
     const int t_sm = FULLW ? ((it_t + NQT - 1) & (NQT - 1)) : it_t, t_s0 = it_t, t_sp = FULLW ? ((it_t + 1) & (NQT - 1)) : it_t + 1; \
     const int t_dsth = (it_r0 * NQT + it_t) * REC + ((2 * it_o) ^ (((it_r0 * NQT + it_t) >> 2) & 3)) * 16 + it_hf * 8; \
     const int t_dstl = t_dsth ^ 16;                 /* the lo unit of the record */                             \
-    _Pragma("nounroll") for (int rep = 0; rep < (EXP >= 2 && EXP <= 6 ? 0 : NREP); ++rep) {                                 \
+    _Pragma("nounroll") for (int rep = 0; rep < ((EXP >= 2 && EXP <= 6) ? 0 : NREP); ++rep) {                                 \
         /* block 0 of the coming multiply phase: fetched one round (~1000 cycles) before the phase barrier */   \
         if (rep == NREP - 1 && EXP != 6) { QGX_W_LOAD(0, WSTEP) }                                                         \
         if (NREP * RR == PR || it_r0 + rep * RR < PR) {                                                         \
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
                 }                                                                                               \
             }                                                                                                   \
         }                                                                                                       \
+    }                                                                                                           \
     }                                                                                                           \
     __builtin_amdgcn_s_setprio(0);
 
