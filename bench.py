@@ -399,6 +399,9 @@ def main():
                          'f32 = exact f32 MFMA')
     ap.add_argument('--no-aux', action='store_true', help='skip the steady / exact_f32 / b1 / b1024 / config3 / config4 legs')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-preheat', action='store_true',
+                    help='profiling runs (profiles/): skip the 0.3 s of generator forwards in front of the timed region, so that the '
+                         'per-kernel call counts of rocprofv3 are those of the warm-up + timed steps')
     ap.add_argument('--one-stream', action='store_true',
                     help='config3 leg: never advance the ensemble as two halves on two streams (PMC passes of profiles/)')
     ap.add_argument('--leg', default='all', choices=['all', 'config3', 'config4', 'b1', 'b1024'],
@@ -468,7 +471,7 @@ def main():
     # finds it in a low power state, and the driver's "--steps 20" timed region is 15 ms long — shorter than the clock ramp
     # (the same engine measured 6 % faster a few seconds later: `steady`).  0.3 s of generator forwards on scratch tensors.
     preheat_s = 0.0
-    if True:
+    if not args.no_preheat:
         xs_ = torch.randn((B, gen.n_in, N, N), dtype=torch.float32, device='cuda')
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.3:

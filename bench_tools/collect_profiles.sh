@@ -7,8 +7,8 @@ set -e
 OUT=$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-H="--steps 50 --warmup 5 --no-aux --no-cpu-baseline"
-P="--steps 5 --warmup 2 --no-aux --no-cpu-baseline"
+H="--steps 200 --warmup 20 --no-aux --no-cpu-baseline --no-preheat"
+P="--steps 5 --warmup 2 --no-aux --no-cpu-baseline --no-preheat"
 M="GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_headline -- python bench.py $H > $OUT/headline.json 2> /dev/null
 echo headline stats done

@@ -153,6 +153,7 @@ int main(int argc, char **argv) {
         else if (exp == 10) run_shape<64, 64, 8, 10>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 11) run_shape<64, 64, 8, 11>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 12) run_shape<64, 64, 8, 12>(B, hin, dw, dbias, dscale, dshift, drange, 5);
+        else if (exp == 13) run_shape<64, 64, 8, 13>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else run_shape<64, 64, 8>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         std::vector<unsigned long long> st(16 * 512);
         CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));

@@ -128,9 +128,13 @@ typedef struct qgx_param {
  * If `refresh_diag` != 0 the last step also stores ph,u,v (as pyqg keeps them).
  * 256 x 256 grids, p == NULL: the steps of a call that neither refresh ph,u,v nor have a diagnostics increment due
  * are executed by ONE persistent launch that occupies every CU of the device (state in registers, row/column exchange
- * in the XCDs' L2); a flag raised inside it (a bounded wait timed out because other work held CUs for seconds) is
- * reported as QGX_ERR_HIP by the NEXT call that touches the model, whose state is then undefined.  Issue such calls
- * on one stream at a time. */
+ * in the XCDs' L2).  Such a run is a transaction: it writes only buffers that hold nothing live, and a flag raised inside
+ * it (a bounded wait timed out because other work held CUs) is found by the NEXT call that touches the model, which restores
+ * the bookkeeping of before the run, switches the kernel off for this model (qgx_run_kernel_state = -1) and replays the
+ * steps with three launches each — the run degrades, the state is never undefined.  Issue such calls on one stream at a
+ * time (a settle from another stream waits for the replay).
+ * Two half-ensembles on two streams (qgx_step_streams): every exit joins both internal streams into `stream`; a call that
+ * failed after one half had advanced marks the handle invalid — every later call returns QGX_ERR_STATE with the reason. */
 int qgx_step(qgx_model *m, int nsteps_to_run, const qgx_param *p, int refresh_diag, void *stream);
 /* Small grids with a generator attached: an even ensemble may advance as two halves on two internal streams that fork from
  * and join `stream` inside the call (members are independent — the reference runs them as separate processes,
@@ -233,10 +237,6 @@ int qgx_spec_div(const double *ah_dev, const double *bh_dev, double *out_dev, in
 int qgx_real_fma(const double *a_dev, const double *b_dev, double *out_dev, size_t n, double alpha,
                  const double *c_dev, double beta, void *stream);
 
-/* Measurement hook (bench.py roofline leg; no reference counterpart): bracket every launch of
- * conv layer `layer` (0..7, -1 = off) of every net with HIP events on the launch stream;
- * _read synchronises those events, returns their summed duration and the launch count, and
- * clears the record. */
 /* sum += y, sumsq += y*y over Monte-Carlo samples (generate_mean_var, cgan_regression.py:139-146;
  * cvae_regression.py:120-126), accumulated in float64 */
 int qgx_moments_accumulate(const float *y_dev, double *sum_dev, double *sumsq_dev, size_t n, void *stream);
@@ -267,6 +267,9 @@ int qgx_generator_wino_info_n(const qgx_generator *g, int N, int *enabled, int *
  * 25-tap f16x3 kernel, 2 its split-K form (tiny ensembles), 3 1-D Winograd (k_convw), 4 1-D Winograd with the input transform
  * under the MFMAs (k_convw2).  For measurement code (bench.py's roofline names the kernel it times). */
 int qgx_generator_layer2_kernel(const qgx_generator *g, int inet, int B, int N, int *kernel);
+/* Measurement hook (bench.py roofline leg; no reference counterpart): bracket every launch (every n-th: option "prof_every")
+ * of conv layer `layer` (0..7, -1 = off) of every net with HIP events on the launch stream; _read synchronises those events,
+ * returns their summed duration and the launch count, and clears the record. */
 int qgx_generator_profile(qgx_generator *g, int layer);
 int qgx_generator_profile_read(qgx_generator *g, double *total_ms, int64_t *launches);
 

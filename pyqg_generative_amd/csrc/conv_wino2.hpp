@@ -164,9 +164,9 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
             *reinterpret_cast<f32x4 *>(lp_ + URB) = f1_;                                                        \
         }                                                                                                       \
     }
-#define QGX_RAW_LOADS(G, J0, J1)  { if ((G) < n_chunks) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
+#define QGX_RAW_LOADS(G, J0, J1)  { if ((G) < n_chunks && EXP != 13) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
                                                            _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) QGX_RAW_LOAD(j_, (G)) } }
-#define QGX_RAW_STORES(G, U) { if ((G) < n_chunks) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
+#define QGX_RAW_STORES(G, U) { if ((G) < n_chunks && EXP != 13) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
                                                       _Pragma("unroll") for (int j_ = 0; j_ < (U); ++j_) QGX_RAW_STORE(j_) } }
 
     // ---- input transform of the chunk in the raw patch: this team's four positions.  Half-item (row, quad, octet, half
