@@ -154,6 +154,8 @@ int main(int argc, char **argv) {
         else if (exp == 11) run_shape<64, 64, 8, 11>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 12) run_shape<64, 64, 8, 12>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 13) run_shape<64, 64, 8, 13>(B, hin, dw, dbias, dscale, dshift, drange, 5);
+        else if (exp == 14) run_shape<64, 64, 8, 14>(B, hin, dw, dbias, dscale, dshift, drange, 5);
+        else if (exp == 15) run_shape<64, 64, 8, 15>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else run_shape<64, 64, 8>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         std::vector<unsigned long long> st(16 * 512);
         CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));

@@ -164,9 +164,9 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
             *reinterpret_cast<f32x4 *>(lp_ + URB) = f1_;                                                        \
         }                                                                                                       \
     }
-#define QGX_RAW_LOADS(G, J0, J1)  { if ((G) < n_chunks && EXP != 13) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
+#define QGX_RAW_LOADS(G, J0, J1)  { if ((G) < n_chunks && EXP != 13 && EXP != 14 && EXP != 15) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
                                                            _Pragma("unroll") for (int j_ = (J0); j_ < (J1); ++j_) QGX_RAW_LOAD(j_, (G)) } }
-#define QGX_RAW_STORES(G, U) { if ((G) < n_chunks && EXP != 13) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
+#define QGX_RAW_STORES(G, U) { if ((G) < n_chunks && EXP != 13 && EXP != 14 && EXP != 15) { QGX_OPAQUE_TID(tq_) const int q_base = (tq_ & 255) + (team == 0 ? 0 : 256 * UA); \
                                                       _Pragma("unroll") for (int j_ = 0; j_ < (U); ++j_) QGX_RAW_STORE(j_) } }
 
     // ---- input transform of the chunk in the raw patch: this team's four positions.  Half-item (row, quad, octet, half
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
 #endif
 #define QGX_TRANSFORM(TEAM, WSTEP)                                                                              \
     __builtin_amdgcn_s_setprio(QGX_W2_TPRIO);                                                                   \
-    if (EXP == 11) {                                                                                            \
+    if (EXP == 11 || EXP == 14 || EXP == 15) {      /* 14: clean MFMA loop + clean VALU transform, no raw copy; 15: ... and no weight fetch */ \
         float xf_[16];                                                                                          \
         _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) xf_[k_] = 1.0f + 0.001f * (lane + k_);                \
         _Pragma("unroll") for (int r_ = 0; r_ < 19; ++r_)                                                       \
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
         float sf_ = 0.f;                                                                                        \
         _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) sf_ += xf_[k_];                                       \
         if (sf_ == 12345.f) ep[0] = sf_;                                                                        \
-        QGX_W_LOAD(0, WSTEP)                                                                                    \
+        if (EXP != 15) { QGX_W_LOAD(0, WSTEP) }                                                                 \
     } else {                                                                                                    \
     QGX_OPAQUE_TID(tt_)                                                                                         \
     tt_ &= 255;                                                                                                 \
@@ -249,6 +249,9 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
     // at the END of the team's transform phase in front of it (the transform's registers are free by then, and the team
     // usually waits at the phase barrier for its partner's MFMAs anyway), so nothing of the ring is live during a transform
     h8 W3[3][2][2];
+#ifndef QGX_W2_SPREAD
+#define QGX_W2_SPREAD 0
+#endif
 #define QGX_W_LOAD(SLOT, S)                                                                                    \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                           \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
@@ -277,9 +280,19 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
         _Pragma("unroll") for (int gi = 0; gi < KY * MT; ++gi) {                                                \
             const int ky = gi / MT, mt = gi % MT;                                                               \
             if (mt == 0) { QGX_W2_STAMP(10 + ky) }                                                              \
-            if (mt == 0 && ky + 2 < KY && EXP != 3 && EXP != 5) {                                               \
-                QGX_W_LOAD((ky + 2) % 3, (CH) * KY + ky + 2)                                                    \
-                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                                              \
+            if (ky + 2 < KY && EXP != 3 && EXP != 5) {                                                          \
+                /* the four 1-KB fetches of the block after next: in a row at the head of the block, or (QGX_W2_SPREAD) */ \
+                /* one in front of each group.  A fetch costs the matrix pipe ~18 cycles (bench_tools/coissue.hip: 35.1  */ \
+                /* against 32.2 cycles per MFMA), more while the partner wave fetches too (41 in a row, 36 spread in the */ \
+                /* microbenchmark); in this kernel the two orders time the same (301.7 / 303.1 us), the row is kept      */ \
+                const int q0_ = QGX_W2_SPREAD ? mt * 4 / MT : (mt == 0 ? 0 : 4);                            \
+                const int q1_ = QGX_W2_SPREAD ? (mt + 1) * 4 / MT : 4;                                      \
+                _Pragma("unroll") for (int q = q0_; q < q1_; ++q)                                               \
+                    W3[(ky + 2) % 3][q >> 1][q & 1] = *reinterpret_cast<const h8 *>(                            \
+                        wb + (size_t)((CH) * KY + ky + 2) * WSLICE + wofs + (q & 1) * 2 * COUT * 16 + (q >> 1) * 32 * 16); \
+                if (q1_ - q0_ == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                          \
+                if (q1_ - q0_ == 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                          \
+                if (q1_ - q0_ == 4) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);                          \
             }                                                                                                   \
             if (gi == 2 * MT && (LOADS)) {          /* behind the last weight fetch of the phase: vmcnt retires in order */ \
                 __builtin_amdgcn_sched_barrier(0);                                                              \
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
             QGX_W2_STAMP(1)
             QGX_RAW_LOADS(ti * NCH + 1, 0, UA)
             { QGX_TRANSFORM(0, 0) }
-            if (EXP != 6 || ti == 0) { QGX_W_LOAD(1, 1) }
+            if ((EXP != 6 || ti == 0) && EXP != 15) { QGX_W_LOAD(1, 1) }
             if (EXP == 6 && ti == 0) { QGX_W_LOAD(0, 0) }
             QGX_W2_STAMP(3)
             QGX_LDS_BARRIER();
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
                 if (ch + 1 < NCH) {
                     QGX_RAW_LOADS(g + 2, 0, UA)
                     { QGX_TRANSFORM(0, (ch + 1) * KY) }
-                    if (EXP != 6) { QGX_W_LOAD(1, (ch + 1) * KY + 1) }
+                    if (EXP != 6 && EXP != 15) { QGX_W_LOAD(1, (ch + 1) * KY + 1) }
                 }
                 QGX_W2_STAMP(3)
                 QGX_LDS_BARRIER();
@@ -441,7 +454,7 @@ __global__ __launch_bounds__(512) void k_convw2(ConvWArgs a, int total_tiles) {
                 QGX_LDS_BARRIER();                  // this team has read the last pixel of the chunk
                 QGX_W2_STAMP(5)
                 QGX_RAW_STORES(g + 1, UB)
-                if (EXP != 6 || g == 0) { QGX_W_LOAD(1, ch * KY + 1) }
+                if ((EXP != 6 || g == 0) && EXP != 15) { QGX_W_LOAD(1, ch * KY + 1) }
                 if (EXP == 6 && g == 0) { QGX_W_LOAD(0, 0) }
                 QGX_W2_STAMP(6)
                 QGX_LDS_BARRIER();
