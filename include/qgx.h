@@ -203,12 +203,15 @@ typedef struct qgx_cnn_weights {      /* host pointers, float32, PyTorch layouts
     float bn_eps;                     /* 1e-5                                        */
 } qgx_cnn_weights;
 
+/* nets: GAN / VAE — the generator / decoder (n_in 4), optionally followed by the regression net `net_mean` (n_in 2) of a
+ * model trained with regression != 'None' (cgan_regression.py:59-60, cvae_regression.py:49-50): n_nets 1 or 2;
+ * GZ — net_mean, net_var (n_in 2): n_nets 2 (mean_var_model.py:82-100). */
 int qgx_generator_create(int kind, const qgx_cnn_weights *nets, int n_nets,
                          const float x_std[2], const float y_std[2], int device,
                          qgx_generator **out);
 int qgx_generator_destroy(qgx_generator *g);
-/* S = y_std * G([q/x_std, z]) (cgan_regression.py:157-162; cvae_regression.py:131-136;
- * mean_var_model.py:105-109).  demean != 0 also applies parameterization.py:25.
+/* S = y_std * G([q/x_std, z]) — with a regression net S = y_std * (G([q/x_std, z]) + net_mean(q/x_std)), summed in
+ * float32 — (cgan_regression.py:157-162; cvae_regression.py:131-136; mean_var_model.py:105-109).  demean != 0 also applies parameterization.py:25.
  * z is float for GAN/VAE, double for GZ. */
 int qgx_generator_forward(qgx_generator *g, const double *q_dev, const void *z_dev,
                           double *S_dev, int B, int N, int demean, void *stream);

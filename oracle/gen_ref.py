@@ -147,7 +147,8 @@ def demean(x):
 
 
 class GeneratorRef:
-    """One of 'gan' | 'vae' | 'gz'.  nets: [G] / [decoder] / [net_mean, net_var]."""
+    """One of 'gan' | 'vae' | 'gz'.  nets: [G] / [decoder] / [net_mean, net_var]; 'gan' / 'vae' with a second net:
+    regression != 'None', nets = [G | decoder, net_mean] (cgan_regression.py:59-60, cvae_regression.py:49-50)."""
 
     def __init__(self, kind, nets, x_std, y_std):
         assert kind in ('gan', 'vae', 'gz')
@@ -171,16 +172,22 @@ class GeneratorRef:
             var = F.softplus(torch.as_tensor(cnn_forward(self.nets[1], X))).numpy()
             return self.y_scale.denormalize(mean + noise * var ** 0.5).squeeze().astype('float64')
         Y = cnn_forward(self.nets[0], np.concatenate([X, noise.astype('float32')], axis=1))
+        if len(self.nets) == 2:                                           # regression != 'None': cgan_regression.py:160-161
+            Y += cnn_forward(self.nets[1], X)
         return self.y_scale.denormalize(Y).squeeze().astype('float64')    # cgan_regression.py:157-162
 
-    def predict_mean_snapshot(self, q, M=100, rng=None):
+    def predict_mean_snapshot(self, q, M=100, rng=None, z=None):
+        """z: the M latent fields (M, 2, N, N) instead of drawing them from rng"""
         X = self.x_scale.normalize(q.astype('float32'))
         if self.kind == 'gz':                                             # mean_var_model.py:111-115
             return self.y_scale.denormalize(cnn_forward(self.nets[0], X)).squeeze().astype('float64')
         rng = rng if rng is not None else np.random
         XX = np.tile(X, (M, 1, 1, 1))                                      # cgan_regression.py:164-171
-        z = rng.randn(M, self.n_latent, X.shape[2], X.shape[3]).astype('float32')
+        if z is None:
+            z = rng.randn(M, self.n_latent, X.shape[2], X.shape[3]).astype('float32')
         Y = cnn_forward(self.nets[0], np.concatenate([XX, z], axis=1)).mean(0, keepdims=True)
+        if len(self.nets) == 2:                                           # cgan_regression.py:169-170
+            Y += cnn_forward(self.nets[1], X)
         return self.y_scale.denormalize(Y).squeeze().astype('float64')
 
 

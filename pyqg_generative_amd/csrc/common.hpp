@@ -95,12 +95,13 @@ struct SpecDev {
 };
 
 // Work the spectral step kernel does on the generator's behalf (small grids in layer-split form, GAN / VAE):
-//  * y != null: the forcing is still the net's raw output (B,2,N,N) float; the kernel's prologue does what k_finish<false>
+//  * y != null: the forcing is still the net's raw output (B,2,N,N) float; the kernel's prologue does what k_finish<FIN_PLAIN>
 //    does — S = double(y * y_std) - mean_{y,x} — with the same arithmetic and summation order, and stores S;
 //  * X != null: the kernel's epilogue assembles the NEXT step's network input from q^{n+1} and fresh white noise,
 //    X = [float(q)/x_std, z], z = b * xi(Philox; seed, member, step) — what k_prep_noise does with a == 0.
 struct GenFuse {
     const float *y = nullptr;
+    const float *y1 = nullptr;      // regression net's output, summed with y in float32 before the scaling (k_finish<FIN_SUM>)
     float ys[2] = {1.f, 1.f};
     int demean = 0;
     unsigned *range = nullptr;      // the generator's range-guard words (conv.hip)

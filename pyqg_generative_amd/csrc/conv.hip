@@ -651,6 +651,15 @@ __global__ void k_prep_input(const double *q, const float *z, float *X, int n_in
     input_absmax(m, range);
 }
 
+// the normalised PV of every member (channels 0, 1 of the generator's 4-channel input) as the 2-channel input of the
+// regression net (cgan_regression.py:159-161: apply_function(self.net_mean, X) on the same X)
+__global__ void k_take2(const float *X, float *X2, int npix2) {      // npix2 = 2 npix, a multiple of 4
+    const int b = blockIdx.y;
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(X + (size_t)b * 2 * npix2);
+    f32x4 *dst = reinterpret_cast<f32x4 *>(X2 + (size_t)b * npix2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npix2 / 4; i += gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 __global__ void k_absmax(const float *x, size_t n, unsigned *range) {
     float m = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -707,8 +716,11 @@ __global__ void k_prep_noise(const double *q, float *z, const float *xi_ext, flo
 // Fused output scaling + per-layer de-mean: one workgroup per (member, layer).
 //   GAN/VAE: S = double(y * y_std)                         (cgan_regression.py:162)
 //   GZ:      S = (mean + z sqrt(softplus(var))) * y_std    (mean_var_model.py:14-17,105-109)
+//   GAN/VAE with regression != 'None': S = double((y + net_mean(x)) * y_std), the sum in float32
+//                                                          (cgan_regression.py:159-162, cvae_regression.py:133-136)
 //   then S -= mean_{y,x} S                                 (parameterization.py:25)
-template <bool GZ>
+enum { FIN_PLAIN = 0, FIN_GZ = 1, FIN_SUM = 2 };
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_finish(const float *y0, const float *y1, const double *z, double *S, int npix, float ys0,
                                                  float ys1, int demean, unsigned *range) {
     __shared__ double sm[16];
@@ -716,10 +728,12 @@ __global__ __launch_bounds__(1024) void k_finish(const float *y0, const float *y
     const size_t o = (size_t)blockIdx.x * npix;
     const float ys = (blockIdx.x & 1) ? ys1 : ys0;
     auto value = [&](int i) -> double {
-        if constexpr (GZ) {
+        if constexpr (MODE == FIN_GZ) {
             const float vr = y1[o + i];
             const float sp = vr > 20.f ? vr : log1pf(expf(vr));
             return ((double)y0[o + i] + z[o + i] * (double)sqrtf(sp)) * (double)ys;
+        } else if constexpr (MODE == FIN_SUM) {
+            return (double)((y0[o + i] + y1[o + i]) * ys);
         } else {
             return (double)(y0[o + i] * ys);
         }
@@ -2137,7 +2151,7 @@ static int reserve(qgx_generator *g, int B, int N) {
     g->cap_elems = 0;
     QGX_HIP(hipMalloc((void **)&g->actA, need * 128 * sizeof(float)));
     QGX_HIP(hipMalloc((void **)&g->actB, need * 64 * sizeof(float)));
-    QGX_HIP(hipMalloc((void **)&g->X, need * 4 * sizeof(float)));
+    QGX_HIP(hipMalloc((void **)&g->X, need * 6 * sizeof(float)));    // (B, 4, N, N), and behind it (B, 2, N, N) for a regression net
     QGX_HIP(hipMalloc((void **)&g->Y0, need * 2 * sizeof(float)));
     QGX_HIP(hipMalloc((void **)&g->Y1, need * 2 * sizeof(float)));
     g->cap_elems = need;
@@ -2374,7 +2388,7 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
         hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)nullptr, g->X, 2, npix, g->x_std[0], g->x_std[1], g->range_dev);
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
         if ((rc = cnn_forward(g, g->nets[1], g->X, g->Y1, B, N, st))) return rc;
-        hipLaunchKernelGGL(k_finish<true>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)g->Y1,
+        hipLaunchKernelGGL(k_finish<FIN_GZ>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)g->Y1,
                            (const double *)z, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
     } else {
         if (input_ready) {
@@ -2387,12 +2401,22 @@ int generator_forward(qgx_generator *g, const double *q, const void *z, double *
         } else {
             hipLaunchKernelGGL(k_prep_input, pg, pb, 0, st, q, (const float *)z, g->X, 4, npix, g->x_std[0], g->x_std[1], g->range_dev);
         }
+        const bool regression = g->n_nets == 2;     // regression != 'None': Y += net_mean(X) on the normalised PV alone
+        if (regression) {
+            float *X2 = g->X + (size_t)B * 4 * npix;
+            hipLaunchKernelGGL(k_take2, dim3((2 * npix / 4 + 255) / 256, B), pb, 0, st, (const float *)g->X, X2, 2 * npix);
+            if ((rc = cnn_forward(g, g->nets[1], X2, g->Y1, B, N, st))) return rc;
+        }
         if ((rc = cnn_forward(g, g->nets[0], g->X, g->Y0, B, N, st))) return rc;
         if (defer) {
-            defer->y = g->Y0; defer->ys[0] = g->y_std[0]; defer->ys[1] = g->y_std[1]; defer->demean = demean;
+            defer->y = g->Y0; defer->y1 = regression ? g->Y1 : nullptr;
+            defer->ys[0] = g->y_std[0]; defer->ys[1] = g->y_std[1]; defer->demean = demean;
             defer->range = g->range_dev;
+        } else if (regression) {
+            hipLaunchKernelGGL(k_finish<FIN_SUM>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)g->Y1,
+                               (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
         } else {
-            hipLaunchKernelGGL(k_finish<false>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)nullptr,
+            hipLaunchKernelGGL(k_finish<FIN_PLAIN>, dim3(2 * B), dim3(1024), 0, st, (const float *)g->Y0, (const float *)nullptr,
                                (const double *)nullptr, S, npix, g->y_std[0], g->y_std[1], demean, g->range_dev);
         }
     }
@@ -2408,7 +2432,9 @@ extern "C" int qgx_generator_create(int kind, const qgx_cnn_weights *nets, int n
                                     const float y_std[2], int device, qgx_generator **out) {
     QGX_REQUIRE(nets && out && x_std && y_std, "qgx_generator_create: null argument");
     QGX_REQUIRE(kind == QGX_GEN_GAN || kind == QGX_GEN_VAE || kind == QGX_GEN_GZ, "unknown generator kind %d", kind);
-    QGX_REQUIRE(n_nets == (kind == QGX_GEN_GZ ? 2 : 1), "generator kind %d needs %d nets", kind, kind == QGX_GEN_GZ ? 2 : 1);
+    // GAN / VAE: the generator or decoder, and optionally (regression != 'None', cgan_regression.py:59-60) the 2-channel net_mean
+    QGX_REQUIRE(kind == QGX_GEN_GZ ? n_nets == 2 : (n_nets == 1 || n_nets == 2), "generator kind %d needs %s nets, not %d", kind,
+                kind == QGX_GEN_GZ ? "2" : "1 or 2", n_nets);
     QGX_HIP(hipSetDevice(device));
     qgx_generator *g = new (std::nothrow) qgx_generator();
     if (!g) { set_error("out of host memory"); return QGX_ERR_NOMEM; }
@@ -2416,7 +2442,7 @@ extern "C" int qgx_generator_create(int kind, const qgx_cnn_weights *nets, int n
     for (int i = 0; i < 2; ++i) { g->x_std[i] = x_std[i]; g->y_std[i] = y_std[i]; }
     for (int n = 0; n < n_nets; ++n) {
         const qgx_cnn_weights *w = &nets[n];
-        const int want_in = kind == QGX_GEN_GZ ? 2 : 4;
+        const int want_in = kind == QGX_GEN_GZ || n == 1 ? 2 : 4;
         if (w->n_in != want_in || w->n_out != 2) {
             set_error("net %d: n_in=%d n_out=%d, expected %d and 2", n, w->n_in, w->n_out, want_in);
             qgx_generator_destroy(g);

@@ -156,19 +156,20 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     if (a.has_S) {
         const double *S0 = a.S + ro, *S1 = S0 + rz;
         if (LSPLIT && a.gf.y) {
-            // the generator's output kernel folded in (k_finish<false>, conv.hip: same arithmetic, same summation order —
+            // the generator's output kernel folded in (k_finish<FIN_PLAIN>, conv.hip: same arithmetic, same summation order —
             // 1024 threads, per-thread partial sums over u, wave shuffles, waves in order): S = double(y * y_std) - mean
             constexpr int KEEP = 16;
             __shared__ double fin_sm[16];
             __shared__ double fin_mean;
             const float *yk = a.gf.y + ((size_t)b * 2 + kown) * rz;
+            const float *y1k = a.gf.y1 ? a.gf.y1 + ((size_t)b * 2 + kown) * rz : nullptr;   // (k_finish<FIN_SUM>)
             const float ys = a.gf.ys[kown];
             double keep[KEEP];
             double acc = 0.0;
 #pragma unroll
             for (int u = 0; u < KEEP; ++u) {
                 const int i = u * (int)blockDim.x + (int)threadIdx.x;
-                keep[u] = i < rz ? (double)(yk[i] * ys) : 0.0;
+                keep[u] = i < rz ? (double)((y1k ? yk[i] + y1k[i] : yk[i]) * ys) : 0.0;
                 acc += keep[u];
             }
             double mu = 0.0;

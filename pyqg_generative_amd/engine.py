@@ -23,7 +23,8 @@ def _stream():
 
 
 class Generator:
-    """Device-resident generator (CGAN G / CVAE decoder / GZ mean+var nets)."""
+    """Device-resident generator (CGAN G / CVAE decoder, each optionally with the regression net `net_mean` as a second
+    net / GZ mean+var nets)."""
     KINDS = {'gan': _lib.GEN_GAN, 'vae': _lib.GEN_VAE, 'gz': _lib.GEN_GZ}
 
     def __init__(self, kind, nets, x_std, y_std, device=0):
@@ -158,7 +159,8 @@ class Generator:
 
     def cnn_forward(self, x, inet=0):
         """Raw AndrewCNN forward: x (B,n_in,N,N) float32 -> (B,2,N,N) float32."""
-        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == self.n_in
+        n_in = 2 if (self.kind == 'gz' or inet == 1) else 4          # net 1 of a GAN / VAE generator: the regression net
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == n_in
         B, _, N, _ = x.shape
         y = torch.empty((B, 2, N, N), dtype=torch.float32, device=x.device)
 

@@ -8,9 +8,27 @@ from .parameterization import Parameterization
 from ..tools.cnn_tools import apply_function
 
 
+REGRESSIONS = ('None', 'full_loss', 'residual_loss')
+
+
 class _LatentCNN(Parameterization):
-    """Shared by the CGAN generator and the CVAE decoder: S = y_std * Net([q/x_std, z])."""
+    """Shared by the CGAN generator and the CVAE decoder: S = y_std * Net([q/x_std, z]), and with regression != 'None'
+    S = y_std * (Net([q/x_std, z]) + net_mean(q/x_std)) (cgan_regression.py:157-162, cvae_regression.py:131-136; the two
+    regression modes differ in training only)."""
     n_latent = 2
+
+    def _set_regression(self, regression):
+        if regression not in REGRESSIONS:
+            raise ValueError(f'regression must be one of {REGRESSIONS}')
+        self.regression = regression
+        if regression != 'None':
+            self.NET_NAMES = tuple(type(self).NET_NAMES[:1]) + ('net_mean',)
+
+    def _mean_correction(self, X):
+        """net_mean(X) for normalised PV X (B,2,N,N) float32 numpy, or 0 without a regression net"""
+        if self.regression == 'None':
+            return 0.0
+        return apply_function(self.net_mean, X)
 
     def generate_latent_noise(self, ny, nx):
         return np.random.randn(1, self.n_latent, ny, nx).astype('float32')
@@ -36,6 +54,7 @@ class _LatentCNN(Parameterization):
         if seed is None:
             z = np.random.randn(M, self.n_latent, q.shape[-2], N).astype('float32')
             Y = apply_function(getattr(self, self.NET_NAMES[0]), np.tile(X, (M, 1, 1, 1)), z, fun=self.generate).mean(0, keepdims=True)
+            Y = Y + self._mean_correction(X)
         else:
             from .._lib import lib, check
             from ..engine import _ptr, _stream
@@ -45,6 +64,7 @@ class _LatentCNN(Parameterization):
             check(lib.qgx_noise_normal(_ptr(z), 0, M, 2 * N * N, int(seed), 0, 0, 0.0, 1.0, _stream()))
             x[:, 2:] = z
             Y = self._gen.cnn_forward(x).to(torch.float64).mean(0, keepdim=True).cpu().numpy().astype('float32')
+            Y = Y + self._mean_correction(X)
         return self.y_scale.denormalize(Y).squeeze().astype('float64')
 
     def predict(self, ds, M=1000, seed=0):
@@ -96,8 +116,9 @@ class _LatentCNN(Parameterization):
             first = self._gen.guarded_loop(draws)
             sm, sq = ssum.cpu().numpy(), ssq.cpu().numpy()
             mu = sm / M
-            sample[s0:s0 + b] = first.cpu().numpy().astype('float64') * ys
-            mean[s0:s0 + b] = mu * ys
+            corr = self._mean_correction(X)         # Y += mean_correction; mean += mean_correction (cgan_regression.py:176-179)
+            sample[s0:s0 + b] = (first.cpu().numpy() + np.asarray(corr, dtype='float32')).astype('float64') * ys
+            mean[s0:s0 + b] = (mu + corr) * ys
             var[s0:s0 + b] = np.maximum(sq - M * mu * mu, 0.0) / max(M - 1, 1) * ys ** 2
         return sample, mean, var
 
@@ -108,10 +129,10 @@ class CGANRegression(_LatentCNN):
 
     def __init__(self, regression='None', nx=64, generator='Andrew', folder='model', div=False,
                  hidden_channels=[128, 64, 32, 32, 32, 32, 32], device=0):
-        if regression != 'None' or generator != 'Andrew' or div or \
-                list(hidden_channels) != [128, 64, 32, 32, 32, 32, 32]:
-            raise NotImplementedError('only the shipped configuration (regression="None", '
-                                      'generator="Andrew", div=False) has a device path')
-        self.regression, self.generator, self.nx, self.div = regression, generator, nx, div
+        if generator != 'Andrew' or div or list(hidden_channels) != [128, 64, 32, 32, 32, 32, 32]:
+            raise NotImplementedError('only generator="Andrew", div=False with the default hidden channels has a device path')
+        self._set_regression(regression)
+        self.generator, self.nx, self.div = generator, nx, div
         self.hidden_channels = hidden_channels
-        self._load(folder, device)          # needs G.pt, x_scale.json, y_scale.json (D.pt is training-only)
+        # needs G.pt, x_scale.json, y_scale.json (D.pt is training-only), and net_mean.pt with regression != 'None'
+        self._load(folder, device)

@@ -9,7 +9,8 @@ class CVAERegression(_LatentCNN):
     NET_NAMES = ('decoder',)
 
     def __init__(self, regression='None', folder='model', div=False, decoder_var='adaptive', device=0, **kw):
-        if regression != 'None' or div:
-            raise NotImplementedError('only regression="None", div=False has a device path')
-        self.regression, self.div, self.decoder_var = regression, div, decoder_var
-        self._load(folder, device)          # needs decoder.pt (the encoder is training-only)
+        if div:
+            raise NotImplementedError('only div=False has a device path')
+        self._set_regression(regression)
+        self.div, self.decoder_var = div, decoder_var
+        self._load(folder, device)          # needs decoder.pt (the encoder is training-only), net_mean.pt with regression != 'None'

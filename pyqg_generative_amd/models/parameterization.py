@@ -21,7 +21,7 @@ class Parameterization(QParameterization):
 
     def _load(self, folder, device=0):
         self.folder = folder
-        nets, xs, ys = _weights.load_folder(folder, self.kind)
+        nets, xs, ys = _weights.load_folder(folder, self.kind, regression=getattr(self, 'regression', 'None') != 'None')
         self.x_scale = ChannelwiseScaler(xs)
         self.y_scale = ChannelwiseScaler(ys)
         self._gen = Generator(self.kind, nets, xs, ys, device=device)
@@ -40,7 +40,12 @@ class Parameterization(QParameterization):
         """Build from in-memory weights (fixtures, synthetic) instead of a model folder."""
         self = cls.__new__(cls)
         self.folder = None
-        self.regression = 'None'
+        # a second net beside a generator / decoder is the regression net (cgan_regression.py:59-60)
+        self.regression = kw.get('regression', 'full_loss' if cls.kind != 'gz' and len(nets) == 2 else 'None')
+        if (self.regression != 'None') != (cls.kind != 'gz' and len(nets) == 2):
+            raise ValueError("regression != 'None' takes two nets (generator / decoder, net_mean); 'None' one")
+        if self.regression != 'None':
+            self.NET_NAMES = tuple(cls.NET_NAMES[:1]) + ('net_mean',)
         self.n_latent = 2
         self.x_scale = ChannelwiseScaler(x_std)
         self.y_scale = ChannelwiseScaler(y_std)

@@ -34,12 +34,15 @@ def net_from_npz(d, prefix):
                 bn_v=[np.asarray(d[f'{prefix}v{i}'], np.float32) for i in range(7)])
 
 
-def load_npz(path, kind):
-    """-> (nets, x_std, y_std) from a flat fixture written by tests/golden/make_golden.py."""
+def load_npz(path, kind, regression_npz=None):
+    """-> (nets, x_std, y_std) from a flat fixture written by tests/golden/make_golden.py.  regression_npz: 'gan' / 'vae'
+    with a regression net (regression != 'None'), read from net0_ of that second fixture."""
     d = np.load(path, allow_pickle=False)
     nets = [net_from_npz(d, 'net0_')]
     if kind == 'gz':
         nets.append(net_from_npz(d, 'net1_'))
+    elif regression_npz is not None:
+        nets.append(net_from_npz(np.load(regression_npz, allow_pickle=False), 'net0_'))
     return nets, np.asarray(d['x_std'], np.float32), np.asarray(d['y_std'], np.float32)
 
 
@@ -51,10 +54,13 @@ def read_scaler_std(path):
     return np.array(ast.literal_eval(d['std'])).astype('float32').reshape(-1)
 
 
-def load_folder(folder, kind):
-    """Reference model folder -> (nets, x_std, y_std).  kind: 'gan' | 'vae' | 'gz'."""
+def load_folder(folder, kind, regression=False):
+    """Reference model folder -> (nets, x_std, y_std).  kind: 'gan' | 'vae' | 'gz'; regression ('gan' / 'vae' trained with
+    regression != 'None'): the folder also holds net_mean.pt (cgan_regression.py:98-101, cvae_regression.py:75-76)."""
     import torch
     files = {'gan': ['G.pt'], 'vae': ['decoder.pt'], 'gz': ['net_mean.pt', 'net_var.pt']}[kind]
+    if regression and kind != 'gz':
+        files = files + ['net_mean.pt']
     nets = []
     for f in files:
         sd = torch.load(os.path.join(folder, f), map_location='cpu', weights_only=True)
@@ -63,7 +69,7 @@ def load_folder(folder, kind):
         read_scaler_std(os.path.join(folder, 'y_scale.json'))
 
 
-def synthetic(kind, seed=0):
+def synthetic(kind, seed=0, regression=False):
     """Seeded random weights of the architecture (throughput runs without fixtures)."""
     rs = np.random.RandomState(seed)
     hidden = [128, 64, 32, 32, 32, 32, 32]
@@ -82,7 +88,7 @@ def synthetic(kind, seed=0):
                 net['bn_m'].append((0.5 + 0.1 * rs.randn(cout)).astype('float32'))
                 net['bn_v'].append((0.5 + 0.2 * rs.rand(cout)).astype('float32'))
         return net
-    nets = [one(2), one(2)] if kind == 'gz' else [one(4)]
+    nets = [one(2), one(2)] if kind == 'gz' else ([one(4), one(2)] if regression else [one(4)])
     x_std = np.array([7.784383342368528e-06, 1.0471941322975908e-06], np.float32)
     y_std = np.array([7.60611105349307e-12, 1.656513061486578e-13], np.float32)
     return nets, x_std, y_std

@@ -25,9 +25,14 @@ def _engine(N, B, **kw):
 
 
 def _gpu_generator(kind):
+    """kind 'gan' | 'vae' | 'gz', or 'gan+reg' | 'vae+reg': with GZ's net_mean as the regression net (regression != 'None'),
+    the combination tests/golden/make_golden_regression.py ran through the reference"""
     import pyqg_generative_amd as qa
     from pyqg_generative_amd import weights
-    nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind)
+    reg = kind.endswith('+reg')
+    kind = kind[:-4] if reg else kind
+    nets, xs, ys = weights.load_npz(os.path.join(GOLDEN, f'weights_{kind}.npz'), kind,
+                                    regression_npz=os.path.join(GOLDEN, 'weights_gz.npz') if reg else None)
     return qa.Generator(kind, nets, xs, ys)
 
 
@@ -208,6 +213,38 @@ def test_generator_matches_reference_golden_on_the_ensemble_kernels(kind, N):
     assert np.array_equal(Sraw[where[0]], Sraw[where[1]]) and np.array_equal(Sraw[where[0]], Sraw[where[2]])
 
 
+@pytest.mark.parametrize('kind', ['gan', 'vae'])
+@pytest.mark.parametrize('N', [48, 64, 96])
+def test_generator_with_a_regression_net_matches_reference_golden(kind, N):
+    """regression != 'None' (cgan_regression.py:59-60,157-162, cvae_regression.py:49-50,131-136): S = y_std (G([x, z]) +
+    net_mean(x)), the sum in float32.  Vectors from the reference's own classes (tests/golden/make_golden_regression.py), on
+    one member (split-K kernels) and at three positions of a 40-member ensemble (the default ensemble kernels); same 2e-5
+    tolerance as the generators without a regression net."""
+    g = golden('generator_regression.npz')
+    gen = _gpu_generator(kind + '+reg')
+    q0 = g[f'{kind}_{N}_q'].astype('float64')
+    z0 = g[f'{kind}_{N}_z'].reshape(2, N, N)
+    ref, ref_raw = g[f'{kind}_{N}_S'], g[f'{kind}_{N}_Sraw']
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    B = 40
+    rs = np.random.RandomState(12)
+    q = rs.randn(B, 2, N, N) * np.array([7.8e-6, 1.05e-6]).reshape(1, 2, 1, 1)
+    z = rs.randn(B, 2, N, N).astype('float32')
+    where = (0, 23, B - 1)
+    for b in where:
+        q[b], z[b] = q0, z0
+    for sl in (slice(0, 1), slice(0, B)):
+        qd, zd = torch.as_tensor(q[sl]).cuda().contiguous(), torch.as_tensor(z[sl]).cuda().contiguous()
+        S = gen.forward(qd, zd, demean=True).cpu().numpy()
+        Sraw = gen.forward(qd, zd, demean=False).cpu().numpy()
+        for b in [w for w in where if w < S.shape[0]]:
+            assert (np.abs(Sraw[b] - ref_raw) / scale).max() < 2e-5
+            assert (np.abs(S[b] - ref) / scale).max() < 2e-5
+    # the regression net is not a rounding-level term of this fixture
+    plain = _gpu_generator(kind).forward(qd[:1], zd[:1], demean=False).cpu().numpy()[0]
+    assert (np.abs(plain - ref_raw) / scale).max() > 1e-2
+
+
 def test_cnn_layers_match_reference_batched():
     """Batched raw CNN forward (B=5, N=32) against the oracle's torch-CPU restatement."""
     gen = _gpu_generator('gan')
@@ -251,6 +288,8 @@ JET = dict(dt=7200., rek=7e-8, delta=0.1, beta=1e-11)      # tools/parameters.py
     ('vae', 'AR1', 2, 96, 3, 4, JET),
     ('gan', 'AR1', 1, 48, 2, 4, dict(dt=14400.)),           # the notebooks' resolution
     ('vae', 'AR1', -1, 64, 2, 4, dict(dt=14400.)),          # nsteps < 0: the first draw is frozen (stochastic_pyqg.py:42-47)
+    ('gan+reg', 'AR1', 1, 64, 2, 4, dict(dt=14400.)),       # regression != 'None': S = y_std (G + net_mean) (cgan_regression.py:159-162)
+    ('vae+reg', 'constant', 2, 96, 3, 4, JET),
 ], ids=lambda v: str(v) if not isinstance(v, dict) else ('jet' if 'rek' in v else 'eddy'))
 def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd, N, B, nsteps, params):
     """configs[1] (64x64 eddy + CGAN, B=1) and configs[3]'s shard (96x96 jet + CVAE, B=32): the full
@@ -355,7 +394,8 @@ def test_fused_step_noise_follows_pinned_philox_stream():
 
 @pytest.mark.parametrize('kind,N,B,sampling,nd', [('gan', 64, 4, 'AR1', 1), ('vae', 64, 1, 'constant', 1),
                                                   ('vae', 96, 3, 'AR1', 1), ('gan', 48, 5, 'constant', 3),
-                                                  ('gan', 64, 2, 'AR1', 10)])
+                                                  ('gan', 64, 2, 'AR1', 10), ('gan+reg', 64, 3, 'AR1', 1),
+                                                  ('vae+reg', 96, 2, 'constant', 2)])
 def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B, sampling, nd):
     """Layer-split small grids: the generator's output kernel rides in the step kernel's prologue and, for white-in-time
     Philox noise, the next step's input kernel in its epilogue (GenFuse).  Same arithmetic in the same order: the run is

@@ -27,6 +27,28 @@ def test_generator_matches_reference(kind, N):
     assert np.abs(S.mean(axis=(1, 2))).max() <= 1e-6 * scale.max()
 
 
+@pytest.mark.parametrize('kind', ['gan', 'vae'])
+@pytest.mark.parametrize('N', [48, 64, 96])
+def test_generator_with_a_regression_net_matches_reference(kind, N):
+    """regression != 'None' (cgan_regression.py:159-162, cvae_regression.py:133-136): Y += net_mean(X) before the
+    de-normalisation; vectors from the reference's own classes (tests/golden/make_golden_regression.py)."""
+    g = golden('generator_regression.npz')
+    gen = load_generator(kind, regression=True)
+    q = g[f'{kind}_{N}_q'].astype('float64')
+    Sraw = gen.predict_snapshot(q, g[f'{kind}_{N}_z'])
+    S = gen_ref.demean(Sraw)
+    ref_raw, ref = g[f'{kind}_{N}_Sraw'], g[f'{kind}_{N}_S']
+    scale = np.abs(ref).max(axis=(1, 2), keepdims=True)
+    assert np.abs(Sraw - ref_raw).max() <= 2e-6 * np.abs(ref_raw).max()
+    assert (np.abs(S - ref) / scale).max() <= 2e-6
+    # and the regression net does matter in this fixture: without it the answer is far off
+    plain = load_generator(kind).predict_snapshot(q, g[f'{kind}_{N}_z'])
+    assert np.abs(plain - ref_raw).max() > 1e-2 * np.abs(ref_raw).max()
+    if N == 64:                                   # predict_mean_snapshot (cgan_regression.py:164-171), M = 6 given latent fields
+        mean6 = gen.predict_mean_snapshot(q, M=6, z=g[f'{kind}_64_mean6_z'])
+        assert np.abs(mean6 - g[f'{kind}_64_mean6']).max() <= 2e-6 * np.abs(g[f'{kind}_64_mean6']).max()
+
+
 def test_layer_activations_match_reference():
     g = golden('layers.npz')
     w = gen_ref.CNNWeights.from_npz_dict(golden('weights_gan.npz'), 'net0_')
