@@ -134,7 +134,10 @@ typedef struct qgx_param {
  * steps with three launches each — the run degrades, the state is never undefined.  Issue such calls on one stream at a
  * time (a settle from another stream waits for the replay).
  * Two half-ensembles on two streams (qgx_step_streams): every exit joins both internal streams into `stream`; a call that
- * failed after one half had advanced marks the handle invalid — every later call returns QGX_ERR_STATE with the reason. */
+ * failed after one half had advanced marks the handle invalid — every later call returns QGX_ERR_STATE with the reason.
+ * Option "split_adv" = 1 (default 0; small grids in the two-workgroups-per-member form, generator attached): the half of the
+ * step kernel that needs nothing of the forcing runs as a kernel of its own on an internal side stream, forked from and
+ * joined into `stream` inside every step; bit-identical, and measured slower on this stack. */
 int qgx_step(qgx_model *m, int nsteps_to_run, const qgx_param *p, int refresh_diag, void *stream);
 /* Small grids with a generator attached: an even ensemble may advance as two halves on two internal streams that fork from
  * and join `stream` inside the call (members are independent — the reference runs them as separate processes,

@@ -58,6 +58,11 @@ struct ModelOpts {
                                  //   (-1: while 6 B <= 256 | 0 | 1)
     int lsplit = -1;             // small grids: two workgroups per member, one per layer (-1 auto | 0 | 1)
     int spec_threads = 0;        // small grids: threads of the one-workgroup-per-member kernels (0 auto | 256 | 512 | 1024)
+    int split_adv = 0;           // small grids in layer-split form + generator: the half of the step kernel that needs nothing of the forcing
+                                 //   (inversion, advection, its transform) as a kernel of its own on a side stream, under the generator's
+                                 //   layers (0 | 1).  Bit-identical and measured SLOWER almost everywhere (the two cross-stream
+                                 //   dependencies per step cost more than the two transforms taken out of the chain: DESIGN.md section 3.1c),
+                                 //   so it is off unless asked for
     int streams = 0;             // small grids + generator: the two halves of the ensemble on two internal streams (0 auto: 96 x 96, 16..64 even members | 1 never | 2 whenever even)
     int team = 1;                // 256 x 256: XCD-resident runs of unparameterized steps
     int team_min = 2;            //   shortest run handed to that kernel
@@ -199,6 +204,10 @@ struct qgx_model {
     double *dg_acc[qgx::N_DIAGS] = {};
     double2 *dg_z = nullptr;               // large grids: the four work fields of the three-launch increment (spectral_large.hip)
     // the two internal streams of a step in halves (model.hip::qgx_step) and their fork / join events
+    // side stream and fork / join events of the two-kernel step (model.hip::step_core); a half-ensemble uses set adv_slot
+    hipStream_t adv_stream[2] = {nullptr, nullptr};
+    hipEvent_t adv_event[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int adv_slot = 0;
     hipStream_t sub_stream[2] = {nullptr, nullptr};
     hipEvent_t sub_event[3] = {nullptr, nullptr, nullptr};
 };
@@ -221,7 +230,7 @@ bool small_layer_split(const SpecDev &d, const ModelOpts &o);
 // spectral_small.hip
 bool small_path_fits(int N);
 int small_prepare(const SpecDev &d);
-int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStream_t st);
+int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStream_t st, int part = 0);
 int small_q_to_qh(const SpecDev &d, const ModelOpts &o, const double *q, double2 *qh, hipStream_t st);
 int small_qh_to_q(const SpecDev &d, const ModelOpts &o, const double2 *qh, double *q, hipStream_t st);
 int small_invert(const SpecDev &d, const ModelOpts &o, const double2 *qh, double2 *ph, double *u, double *v, hipStream_t st);

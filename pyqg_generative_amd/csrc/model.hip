@@ -32,10 +32,8 @@ int large_team_steps(qgx_model *m, int K, int ablevel0, const double coef[3][3],
                      const double2 *p_src, const double2 *pp_src, double2 *p_dst, double2 *pp_dst, hipStream_t st);
 
 // One _step_forward: AB3 coefficient schedule of kernel.pyx::_forward_timestep, history rotation.
-static int model_step_once(qgx_model *m, bool has_S, const double *S, double weight, int demean, int diag,
-                           hipStream_t st, const GenFuse *gf = nullptr) {
-    StepArgs a;
-    if (gf) a.gf = *gf;
+// the arguments of step n that do not depend on its forcing; advances the AB3 start-up level
+static void step_args_begin(qgx_model *m, int diag, StepArgs &a) {
     const double dt = m->cfg.dt;
     if (m->ablevel == 0) { a.dt1 = dt; a.dt2 = 0.0; a.dt3 = 0.0; m->ablevel = 1; }
     else if (m->ablevel == 1) { a.dt1 = 1.5 * dt; a.dt2 = -0.5 * dt; a.dt3 = 0.0; m->ablevel = 2; }
@@ -44,15 +42,31 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
     a.qh_in = m->qh[m->cur_q];
     a.qh_out = m->qh[m->cur_q ^ 1];
     a.q = m->q;
-    a.S = S;
     a.dqh = m->dqh;
     a.dq_new = m->dq[m->i_pp];
     a.dq_p = m->dq[m->i_new];
     a.dq_pp = m->dq[m->i_p];
     a.ph = m->ph; a.u = m->u; a.v = m->v;
+    a.diag = diag;
+}
+
+// pre: the first half of this step (k_step_small PART 1) is already in flight on the model's side stream with these
+// arguments (step_core); the second half is ordered behind it here
+static int model_step_once(qgx_model *m, bool has_S, const double *S, double weight, int demean, int diag,
+                           hipStream_t st, const GenFuse *gf = nullptr, const StepArgs *pre = nullptr) {
+    StepArgs a;
+    if (pre) a = *pre; else step_args_begin(m, diag, a);
+    if (gf) a.gf = *gf;
+    a.S = S;
     a.weight = weight;
-    a.has_S = has_S ? 1 : 0; a.demean = demean; a.diag = diag;
-    int rc = m->small ? small_step(m->d, m->opts, a, st) : large_step(m, a, st);
+    a.has_S = has_S ? 1 : 0; a.demean = demean;
+    int rc;
+    if (pre) {
+        QGX_HIP(hipStreamWaitEvent(st, m->adv_event[m->adv_slot][1], 0));
+        rc = small_step(m->d, m->opts, a, st, 2);
+    } else {
+        rc = m->small ? small_step(m->d, m->opts, a, st) : large_step(m, a, st);
+    }
     if (rc) return rc;
     const int dead = m->i_pp;
     m->i_pp = m->i_p; m->i_p = m->i_new; m->i_new = dead;
@@ -312,6 +326,8 @@ extern "C" int qgx_destroy(qgx_model *m) {
     for (double *p : m->dg_R) if (p) (void)hipFree(p);
     for (double *p : m->dg_S) if (p) (void)hipFree(p);
     for (double *p : m->dg_acc) if (p) (void)hipFree(p);
+    for (hipStream_t sst : m->adv_stream) if (sst) (void)hipStreamDestroy(sst);
+    for (auto &evs : m->adv_event) for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (hipStream_t sst : m->sub_stream) if (sst) (void)hipStreamDestroy(sst);
     for (hipEvent_t ev : m->sub_event) if (ev) (void)hipEventDestroy(ev);
     delete m;
@@ -416,6 +432,7 @@ extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
     else if (!strcmp(name, "diag_wide")) { QGX_REQUIRE(value >= -1 && value <= 1, "diag_wide must be -1 (auto), 0 or 1"); o.diag_wide = value; }
     else if (!strcmp(name, "diag_reg")) o.diag_reg = value ? 1 : 0;
     else if (!strcmp(name, "lsplit")) { QGX_REQUIRE(value >= -1 && value <= 1, "lsplit must be -1 (auto), 0 or 1"); o.lsplit = value; }
+    else if (!strcmp(name, "split_adv")) { QGX_REQUIRE(value == 0 || value == 1, "split_adv must be 0 or 1"); o.split_adv = value; }
     else if (!strcmp(name, "streams")) { QGX_REQUIRE(value >= 0 && value <= 2, "streams must be 0 (auto), 1 or 2"); o.streams = value; }
     else if (!strcmp(name, "spec_threads")) {
         QGX_REQUIRE(value == 0 || value == 256 || value == 512 || value == 1024, "spec_threads must be 0 (auto), 256, 512 or 1024");
@@ -473,6 +490,22 @@ extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
     return QGX_OK;
 }
 
+// the two-kernel step (k_step_small PART 1 / 2), small grids in layer-split form: option "split_adv" = 1 only
+// (measured, bench_tools/split_adv.py: DESIGN.md section 3.1c)
+static bool step_adv_applies(const qgx_model *m) {
+    if (m->plan_only || !m->small || m->opts.split_adv == 0 || !small_layer_split(m->d, m->opts) || !m->adv_stream[m->adv_slot]) return false;
+    return m->opts.split_adv == 1;
+}
+static int step_adv_ensure(qgx_model *m) {
+    if (!m->small || m->opts.split_adv == 0) return QGX_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (!m->adv_stream[i]) QGX_HIP(hipStreamCreateWithFlags(&m->adv_stream[i], hipStreamNonBlocking));
+        for (int j = 0; j < 2; ++j)
+            if (!m->adv_event[i][j]) QGX_HIP(hipEventCreateWithFlags(&m->adv_event[i][j], hipEventDisableTiming));
+    }
+    return QGX_OK;
+}
+
 // ---- the stepping loop: pyqg model.py::_step_forward with the plugin call of
 // pyqg_generative/models/parameterization.py:23-34 and samplers of stochastic_pyqg.py:30-72
 // the steps of one call on one stream, for the whole ensemble or for one half of it (qgx_step below)
@@ -517,6 +550,10 @@ static int step_core(qgx_model *m, int nsteps, const qgx_param *p, int refresh_d
         int demean_in_kernel = 0;
         GenFuse gf;
         bool use_gf = false;
+        const int diag_now = (refresh_diag && s == nsteps - 1) ? 1 : 0;
+        StepArgs pre;
+        bool have_pre = false;
+        int ablevel_before = m->ablevel;
         if (p && p->gen) {
             weight = p->weight;
             bool compute = true;
@@ -544,6 +581,29 @@ static int step_core(qgx_model *m, int nsteps, const qgx_param *p, int refresh_d
             }
             if (compute) {
                 if (!m->small) { int qrc = large_ensure_q(m, st); if (qrc) return qrc; }
+                // The half of the step kernel that needs nothing of the forcing (inversion, advection products, their
+                // transform, the tendency without its forcing term) on the side stream, under the generator's layers: on an
+                // ensemble that leaves CUs idle the step is a chain of dependent launches, and this takes two of the step
+                // kernel's four transforms out of it.  Not on steps that refresh (psi, u, v) or increment the diagnostics.
+                if (step_adv_applies(m) && !diag_now &&
+                    !(m->dg_every > 0 && m->tc >= 1 && m->tc >= m->dg_start && m->tc % m->dg_every == 0)) {
+                    const int sl = m->adv_slot;
+                    ablevel_before = m->ablevel;
+                    step_args_begin(m, 0, pre);
+                    hipError_t e = hipEventRecord(m->adv_event[sl][0], st);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(m->adv_stream[sl], m->adv_event[sl][0], 0);
+                    if (e != hipSuccess) { m->ablevel = ablevel_before; QGX_HIP(e); }
+                    int arc = small_step(m->d, m->opts, pre, m->adv_stream[sl], 1);
+                    // (whatever was enqueued on the side stream is joined below on every path)
+                    e = hipEventRecord(m->adv_event[sl][1], m->adv_stream[sl]);
+                    if (arc || e != hipSuccess) {
+                        (void)hipStreamSynchronize(m->adv_stream[sl]);
+                        m->ablevel = ablevel_before;
+                        if (arc) return arc;
+                        QGX_HIP(e);
+                    }
+                    have_pre = true;
+                }
                 // Small grids in layer-split form, GAN / VAE: the generator's output kernel rides in the step kernel's
                 // prologue (unless this step's diagnostics need S first) and — white-in-time Philox noise, more steps to
                 // come in this call — the next step's input kernel in its epilogue (GenFuse, common.hpp)
@@ -554,7 +614,13 @@ static int step_core(qgx_model *m, int nsteps, const qgx_param *p, int refresh_d
                 // a redraw always comes with a recompute; the sampler update rides in the input kernel
                 int rc = generator_forward(p->gen, m->q, m->z, m->S, B, N, p->demean, st, draw ? &nu : nullptr,
                                            fusable && !diag_due ? &gf : nullptr, input_ready);
-                if (rc) return rc;
+                if (rc) {
+                    if (have_pre) {        // the first half wrote a dead tendency slot only: the state is that of step n - 1
+                        (void)hipStreamWaitEvent(st, m->adv_event[m->adv_slot][1], 0);
+                        m->ablevel = ablevel_before;
+                    }
+                    return rc;
+                }
                 m->have_forcing = true;
                 const bool white = (p->sampling == QGX_SAMPLING_AR1 && p->nsteps == 1) ||
                                    (p->sampling == QGX_SAMPLING_CONSTANT && p->nsteps == 1);
@@ -579,9 +645,11 @@ static int step_core(qgx_model *m, int nsteps, const qgx_param *p, int refresh_d
             int drc = diag_increment(m, has_S ? S : nullptr, weight, st);
             if (drc) return drc;
         }
-        const int diag = (refresh_diag && s == nsteps - 1) ? 1 : 0;
-        int rc = model_step_once(m, has_S, S, weight, demean_in_kernel, diag, st, use_gf ? &gf : nullptr);
-        if (rc) return rc;
+        int rc = model_step_once(m, has_S, S, weight, demean_in_kernel, diag_now, st, use_gf ? &gf : nullptr, have_pre ? &pre : nullptr);
+        if (rc) {
+            if (have_pre) { (void)hipStreamSynchronize(m->adv_stream[m->adv_slot]); m->ablevel = ablevel_before; }
+            return rc;
+        }
     }
     return QGX_OK;
 }
@@ -613,6 +681,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
     QGX_REQUIRE(m && nsteps >= 0, "qgx_step: bad argument");
     hipStream_t st = (hipStream_t)stream;
     { int trc = team_settle(m, st); if (trc) return trc; }
+    if (p && p->gen && nsteps > 0) { int arc = step_adv_ensure(m); if (arc) return arc; }
     if (nsteps == 0 || !step_in_halves(m, p)) {
         if (p && p->gen) { int wrc = generator_select_workspace(p->gen, 0); if (wrc) return wrc; }
         return step_core(m, nsteps, p, refresh_diag, st);
@@ -649,6 +718,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
             for (int i = 0; i < qgx::N_DIAGS; ++i) k.dg_acc[i] += b0 * (i < 2 ? 2 * s2 : s2);
         }
         k.sub_stream[0] = k.sub_stream[1] = nullptr;
+        k.adv_slot = c;
         pp[c].member_offset = p->member_offset + b0;
     }
     // the halves take turns in chunks of steps (a chunk keeps the fused input / output kernels of consecutive steps fused and

@@ -119,8 +119,14 @@ extern __shared__ __attribute__((aligned(16))) char qgx_smem[];
 // of six, with the single real fields packed as (x + 0 i).  Used while 2B workgroups are all resident
 // (the kernel is a latency chain then: B = 128 at 64x64 leaves half of the CUs idle with one workgroup per
 // member); 8 FFTs per member instead of 6 make it slower once members queue up.
-template <int NN, bool LSPLIT = false>
+// PART (LSPLIT only): the step as two kernels.  1 = the half that needs nothing of the forcing — inversion, (u, v), the
+// advection products and their transform, the tendency without its forcing term, stored in the slot of the new tendency;
+// 2 = the rest — forcing S_k and its transform, tendency + forcing, AB3 update, q_k (and the generator work of GenFuse).
+// Half 1 depends on the previous step alone, so it runs on a side stream UNDER the generator's layers (model.hip); the
+// arithmetic and its order are those of the whole kernel: bit-identical results.
+template <int NN, bool LSPLIT = false, int PART = 0>
 __global__ void k_step_small(SpecDev d, StepArgs a) {
+    static_assert(PART == 0 || LSPLIT, "the two-kernel step exists in layer-split form only");
     double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
     int *pos_lds;
     Grid g = make_grid(d, Z, pos_lds);
@@ -132,7 +138,7 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     const int sz = N * NK, rz = N * N;
     const double2 *qh0 = a.qh_in + so, *qh1 = qh0 + sz;
     float in_max = 0.f;
-    if (LSPLIT && a.gf.X) {
+    if (LSPLIT && PART != 1 && a.gf.X) {
         // next step's latent channel first: it depends on nothing this kernel computes, and here its arithmetic
         // (Philox rounds, log, sincos) runs while the first global loads of the step are in flight
         // latent channel kown: z = b * xi, white in time (k_prep_noise with a == 0; quads of the flat (2, N*N) field)
@@ -153,7 +159,7 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     __syncthreads();
 
     // ---- subgrid forcing: Sh_k = rfft2(weight * S_k), pair packed (pyqg _do_q_subgrid_parameterization)
-    if (a.has_S) {
+    if (PART != 1 && a.has_S) {
         const double *S0 = a.S + ro, *S1 = S0 + rz;
         if (LSPLIT && a.gf.y) {
             // the generator's output kernel folded in (k_finish<FIN_PLAIN>, conv.hip: same arithmetic, same summation order —
@@ -224,56 +230,69 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     }
 
     for (int k = kown; k < (LSPLIT ? kown + 1 : 2); ++k) {
-        // ---- _invert: ph_k, (u_k, v_k) = irfft2(-il ph, ik ph)
-        build_uv(Z, g, d, k, qh0, qh1, a.diag ? a.ph + so + k * sz : nullptr);
-        __syncthreads();
-        fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
-        // ---- _do_advection, real space: uq = (u+U) q, vq = v q
-        {
-            const double *qk = a.q + ro + k * rz;
-            const double Uk = d.U[k];
-            for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
-                const int y = idx / N, x = idx - y * N;
-                const double2 uv = Z[y * LD + x];
-                if (a.diag) { a.u[ro + k * rz + idx] = uv.x; a.v[ro + k * rz + idx] = uv.y; }
-                const double qv = qk[idx];
-                Z[y * LD + x] = make_double2((uv.x + Uk) * qv, uv.y * qv);
+        if constexpr (PART != 2) {
+            // ---- _invert: ph_k, (u_k, v_k) = irfft2(-il ph, ik ph)
+            build_uv(Z, g, d, k, qh0, qh1, a.diag ? a.ph + so + k * sz : nullptr);
+            __syncthreads();
+            fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
+            // ---- _do_advection, real space: uq = (u+U) q, vq = v q
+            {
+                const double *qk = a.q + ro + k * rz;
+                const double Uk = d.U[k];
+                for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+                    const int y = idx / N, x = idx - y * N;
+                    const double2 uv = Z[y * LD + x];
+                    if (a.diag) { a.u[ro + k * rz + idx] = uv.x; a.v[ro + k * rz + idx] = uv.y; }
+                    const double qv = qk[idx];
+                    Z[y * LD + x] = make_double2((uv.x + Uk) * qv, uv.y * qv);
+                }
             }
+            __syncthreads();
+            fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
         }
-        __syncthreads();
-        fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
         // ---- spectral tendency, friction, forcing, AB3 + filter (_forward_timestep)
         for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
             const int j = idx / NK, i = idx - j * NK;
-            double2 uqh, vqh;
-            unpack_pair(Z, g, j, i, uqh, vqh);
-            const double2 q0 = qh0[idx], q1 = qh1[idx];
-            const double2 ph = invert_layer(d, k, idx, q0, q1);
-            const double kx = d.kk[i], ly = d.ll[j];
-            const double kq = kx * d.Qy[k];
-            // -(ik uqh + il vqh + ik Qy ph)
-            double tx = (kx * uqh.y + ly * vqh.y + kq * ph.y);
-            double ty = -(kx * uqh.x + ly * vqh.x + kq * ph.x);
-            if (k == 1 && d.rek != 0.0) {
-                const double f = d.rek * d.wv2[idx];
-                tx += f * ph.x;
-                ty += f * ph.y;
-            }
-            if (a.has_S) {
-                const double2 s = a.dqh[so + k * sz + idx];
-                tx += s.x;
-                ty += s.y;
-            }
             const size_t o = so + k * sz + idx;
-            const double2 p = a.dq_p[o], pp = a.dq_pp[o];
-            const double2 qk = k == 0 ? q0 : q1;
-            const double f = d.filtr[idx];
-            a.dq_new[o] = make_double2(tx, ty);
-            a.qh_out[o] = make_double2(f * (qk.x + a.dt1 * tx + a.dt2 * p.x + a.dt3 * pp.x),
-                                       f * (qk.y + a.dt1 * ty + a.dt2 * p.y + a.dt3 * pp.y));
+            const double2 q0 = qh0[idx], q1 = qh1[idx];
+            double tx, ty;
+            if constexpr (PART != 2) {
+                double2 uqh, vqh;
+                unpack_pair(Z, g, j, i, uqh, vqh);
+                const double2 ph = invert_layer(d, k, idx, q0, q1);
+                const double kx = d.kk[i], ly = d.ll[j];
+                const double kq = kx * d.Qy[k];
+                // -(ik uqh + il vqh + ik Qy ph)
+                tx = (kx * uqh.y + ly * vqh.y + kq * ph.y);
+                ty = -(kx * uqh.x + ly * vqh.x + kq * ph.x);
+                if (k == 1 && d.rek != 0.0) {
+                    const double f = d.rek * d.wv2[idx];
+                    tx += f * ph.x;
+                    ty += f * ph.y;
+                }
+            } else {
+                const double2 t = a.dq_new[o];      // what half 1 stored
+                tx = t.x; ty = t.y;
+            }
+            if constexpr (PART == 1) {
+                a.dq_new[o] = make_double2(tx, ty);
+            } else {
+                if (a.has_S) {
+                    const double2 s = a.dqh[so + k * sz + idx];
+                    tx += s.x;
+                    ty += s.y;
+                }
+                const double2 p = a.dq_p[o], pp = a.dq_pp[o];
+                const double2 qk = k == 0 ? q0 : q1;
+                const double f = d.filtr[idx];
+                a.dq_new[o] = make_double2(tx, ty);
+                a.qh_out[o] = make_double2(f * (qk.x + a.dt1 * tx + a.dt2 * p.x + a.dt3 * pp.x),
+                                           f * (qk.y + a.dt1 * ty + a.dt2 * p.y + a.dt3 * pp.y));
+            }
         }
         __syncthreads();
     }
+    if constexpr (PART == 1) return;
     // ---- q^{n+1} = irfft2(qh^{n+1}), both layers packed (LSPLIT: the own layer alone)
     if (LSPLIT) build_pair(Z, g, a.qh_out + so + kown * sz, nullptr, d.invN2);
     else build_pair(Z, g, a.qh_out + so, a.qh_out + so + sz, d.invN2);
@@ -842,6 +861,8 @@ int small_prepare(const SpecDev &d) {
     QGX_DISPATCH_N(d.N, {
         QGX_HIP(hipFuncSetAttribute((const void *)k_step_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_q_to_qh_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_qh_to_q_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -860,8 +881,14 @@ bool small_layer_split(const SpecDev &d, const ModelOpts &o) {
     return 2 * d.B <= 256;      // one workgroup per CU (measured at 64x64: B = 128 44 -> 33 us, B = 256 55 -> 63 us)
 }
 
-int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStream_t st) {
-    if (small_layer_split(d, o)) {
+// part: 0 the whole step; 1 / 2 its two halves (layer-split form only; k_step_small PART)
+int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStream_t st, int part) {
+    QGX_REQUIRE(part == 0 || small_layer_split(d, o), "small_step: the two-kernel step needs the layer-split form");
+    if (part == 1) {
+        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 1>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
+    } else if (part == 2) {
+        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 2>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
+    } else if (small_layer_split(d, o)) {
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else {
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL(k_step_small<NN>, dim3(d.B), dim3(small_threads(d, o)), small_lds_bytes(d), st, d, a))

@@ -426,6 +426,31 @@ def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('kind,N,B,sampling,nd', [('gan', 64, 3, 'AR1', 1), ('vae', 96, 4, 'constant', 2), ('gan+reg', 48, 2, 'AR1', 4)])
+def test_step_kernel_as_two_kernels_on_two_streams_changes_nothing(kind, N, B, sampling, nd):
+    """Option split_adv: the half of the step kernel that needs nothing of the forcing (inversion, advection products, their
+    transform, the tendency without its forcing term) runs as a kernel of its own on a side stream under the generator's
+    layers, the other half behind both.  Same arithmetic in the same order: bit-identical state, forcing, noise and
+    diagnostics, on whole ensembles and on two half-ensembles (pyqg model.py::_step_forward order of operations)."""
+    import pyqg_generative_amd._lib as L
+    q0 = _eddy_like_q(np.random.RandomState(9), B, N)
+    gen = _gpu_generator(kind)
+    res = []
+    for opts in ({}, dict(split_adv=1), dict(split_adv=1, genfuse=0), dict(streams=2), dict(split_adv=1, streams=2)):
+        e = _engine(N, B, dt=dt_for(N))
+        for opt, val in opts.items():
+            e.set_option(opt, val)
+        e.set_q(q0)
+        e.diag_config(0, 4)
+        for chunk in (7, 1, 9):
+            e.step(chunk, generator=gen, sampling=sampling, nsteps_decor=nd, seed=11, member_offset=3)
+        res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Z, L.F_Q, L.F_U, L.F_PH)] + [e.diag(n).clone() for n in _lib_diags()])
+        e.close()
+    for ref, other in ((0, 1), (0, 2), (3, 4)):      # (the halves against the halves: they may take other generator kernels than the whole)
+        for a, b in zip(res[ref], res[other]):
+            assert torch.equal(a, b)
+
+
 def test_full_size_step_members_are_independent():
     """BASELINE's single-GPU shard (128 members, 64 x 64, GAN): copies of four members spread over the
     ensemble, fed the same external noise, stay bit-identical through parameterized steps, and the
