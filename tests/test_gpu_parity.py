@@ -323,6 +323,7 @@ def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd
         m.set_q(q0[b])
         refs.append(m)
     draws = 0
+    worst_S = worst_q = 0.0
     for s in range(nsteps):
         # the oracle consumes one external draw per sampler refresh: every step for AR1,
         # every nd-th step for the constant sampler (stochastic_pyqg.py:62-71)
@@ -336,9 +337,13 @@ def test_parameterized_steps_match_oracle_with_external_noise(kind, sampling, nd
         S = e.get(L.F_S).cpu().numpy()
         for b, m in enumerate(refs):
             sc = np.abs(m.PV_forcing).max(axis=(1, 2), keepdims=True)
-            assert (np.abs(S[b] - m.PV_forcing) / sc).max() < 5e-5, (s, b)
-            # the f32 generator difference enters qh scaled by dt*|S|/|q| ~ 1e-2 per step
-            assert _rel(qh[b], m.qh) < 2e-6, (s, b)
+            worst_S = max(worst_S, (np.abs(S[b] - m.PV_forcing) / sc).max())
+            worst_q = max(worst_q, _rel(qh[b], m.qh))
+            # the bound the generator alone is held to (measured here: 1e-6 ... 3e-6 of max|S|, profiles/r04_step_parity.txt)
+            assert (np.abs(S[b] - m.PV_forcing) / sc).max() < 2e-5, (s, b)
+            # the f32 generator difference enters qh scaled by dt*|S|/|q| ~ 1e-2 per step (measured: 3e-8 ... 1.5e-7)
+            assert _rel(qh[b], m.qh) < 5e-7, (s, b)
+    print(f'\n{kind} {sampling} {nd} {N} {B}: worst S error {worst_S:.2e} of max|S|, worst qh error {worst_q:.2e}')
 
 
 @pytest.mark.parametrize('mode', ['f32', 'f16x3'])
