@@ -1,5 +1,5 @@
 """Developer tool: the small-grid diagnostics increment, one workgroup per member: work fields in registers (k_diag_small_reg,
-option diag_reg = 1) against work fields in global memory (k_diag_small) — time per increment (HIP events over a run whose every
+option diag_reg = 2; as two workgroups per member: 3) against work fields in global memory (k_diag_small, 0) — time per increment (HIP events over a run whose every
 step increments) and bit identity of the sixteen accumulators.
     python bench_tools/diag_time.py [members] [N]"""
 import os, sys
@@ -15,7 +15,7 @@ S = torch.as_tensor(rs.randn(B, 2, N, N) * 1e-12, device='cuda')
 names = ['KEspec', 'Ensspec', 'entspec', 'APEflux', 'KEflux', 'APEgenspec', 'KEfrictionspec', 'paramspec', 'paramspec_APEflux',
          'paramspec_KEflux', 'Dissspec', 'ENSDissspec', 'ENSflux', 'ENSgenspec', 'ENSfrictionspec', 'ENSparamspec']
 res, t = {}, {}
-for reg in (0, 1):
+for reg in (0, 2, 3):
     for every in (1, 1000000):
         e = qa.EnsembleEngine(nx=N, n_members=B, dt=14400.)
         e.set_option('diag_wide', 0)
@@ -34,7 +34,7 @@ for reg in (0, 1):
             res[reg] = [e.diag(n).clone() for n in names]
         e.close()
     print(f'N={N} B={B} diag_reg={reg}: step with an increment {t[reg, 1]:.1f} us, without {t[reg, 1000000]:.1f} us -> increment {t[reg, 1] - t[reg, 1000000]:.1f} us', flush=True)
-print('accumulators bit-identical:', all(torch.equal(x, y) for x, y in zip(res[0], res[1])))
-for n, x, y in zip(names, res[0], res[1]):
+print('accumulators bit-identical:', all(torch.equal(x, y) and torch.equal(x, z) for x, y, z in zip(res[0], res[2], res[3])))
+for n, x, y in zip(names, res[0], res[3]):
     if not torch.equal(x, y):
         print(f'   {n}: max |diff| / max {float((x - y).abs().max() / x.abs().max()):.2e}')

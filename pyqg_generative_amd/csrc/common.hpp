@@ -53,7 +53,8 @@ constexpr int MAX_RADIX_PASSES = 12;
 struct ModelOpts {
     int genfuse = 1;             // small grids: generator output / next-input kernels folded into the step kernel
     int diag_fused = 1;          // small grids: one-kernel diagnostics increment (0: one launch per transform, diag.hip)
-    int diag_reg = 1;            // small grids up to 64 x 64: the one-kernel increment with its work fields in registers (k_diag_small_reg)
+    int diag_reg = 1;            // small grids up to 64 x 64: the one-kernel increment with its work fields in registers (k_diag_small_reg):
+                                 //   0 off | 1 on, as two workgroups per member while 2 B <= 256 | 2 always one workgroup per member | 3 always two
     int diag_wide = -1;          // small grids: the increment's transforms as (member, transform) workgroups, 3 launches
                                  //   (-1: while 6 B <= 256 | 0 | 1)
     int lsplit = -1;             // small grids: two workgroups per member, one per layer (-1 auto | 0 | 1)

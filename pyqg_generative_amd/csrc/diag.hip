@@ -27,7 +27,7 @@ int small_diag_increment(const SpecDev &d, const DiagConst &c, const double2 *qh
 
 bool small_diag_increment_reg_ok(const SpecDev &d);
 int small_diag_increment_reg(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, const double *S, double weight, const double *q,
-                             const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st);
+                             const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st, bool halves);
 
 int small_diag_transforms_wide(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, double *u, double *v, double *P,
                                double *XI, double2 *S3, double2 *S4, double2 *S5, double2 *Sh, double2 *S6, double2 *S7, const double *S,
@@ -151,7 +151,9 @@ int diag_increment(qgx_model *m, const double *S, double weight, hipStream_t st)
     if (m->small && m->opts.diag_fused && m->opts.diag_reg && small_diag_increment_reg_ok(d)) {
         // grids up to 64 x 64: the same in ONE kernel whose work fields stay in registers (k_diag_small_reg: a quarter of the
         // bytes); it stores ph but no u, v — they are marked stale and inverted on demand
-        rc = small_diag_increment_reg(d, c, qh, m->ph, S, weight, m->q, dq_p, dq_pp, a, st);
+        // ... as two workgroups per member (chains of 7 and 5 transforms instead of one of 10) while both fit the device at once
+        const bool halves = m->opts.diag_reg == 3 || (m->opts.diag_reg == 1 && 2 * d.B <= 256);
+        rc = small_diag_increment_reg(d, c, qh, m->ph, S, weight, m->q, dq_p, dq_pp, a, st, halves);
         if (rc) return rc;
         m->uv_stale = true;
         m->dg_count += 1;

@@ -430,7 +430,7 @@ extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
     if (!strcmp(name, "genfuse")) o.genfuse = value ? 1 : 0;
     else if (!strcmp(name, "diag_fused")) o.diag_fused = value ? 1 : 0;
     else if (!strcmp(name, "diag_wide")) { QGX_REQUIRE(value >= -1 && value <= 1, "diag_wide must be -1 (auto), 0 or 1"); o.diag_wide = value; }
-    else if (!strcmp(name, "diag_reg")) o.diag_reg = value ? 1 : 0;
+    else if (!strcmp(name, "diag_reg")) { QGX_REQUIRE(value >= 0 && value <= 3, "diag_reg must be 0, 1 (auto), 2 (one workgroup per member) or 3 (two)"); o.diag_reg = value; }
     else if (!strcmp(name, "lsplit")) { QGX_REQUIRE(value >= -1 && value <= 1, "lsplit must be -1 (auto), 0 or 1"); o.lsplit = value; }
     else if (!strcmp(name, "split_adv")) { QGX_REQUIRE(value == 0 || value == 1, "split_adv must be 0 or 1"); o.split_adv = value; }
     else if (!strcmp(name, "streams")) { QGX_REQUIRE(value >= 0 && value <= 2, "streams must be 0 (auto), 1 or 2"); o.streams = value; }

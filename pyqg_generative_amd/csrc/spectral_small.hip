@@ -521,7 +521,11 @@ __host__ __device__ constexpr size_t diag_reg_side_offset(int N) {
     return (((size_t)N * (N + 1) * sizeof(double2) + (size_t)((N + 3) & ~3) * sizeof(int) + (size_t)N * sizeof(double2)) + 15) & ~(size_t)15;
 }
 __host__ __device__ constexpr size_t diag_reg_lds_bytes(int N) { return diag_reg_side_offset(N) + (size_t)2 * N * (N / 2 + 1) * sizeof(double2); }
-template <int NN>
+// HALF: the increment of a member as two workgroups (blockIdx = 2 member + half) — 1: the inversion, p, xi and the three
+// product transforms behind APEflux and KEflux (7 transforms in a chain), 2: the inversion, the forcing's transform and the
+// two enstrophy-flux ones, with every other accumulator (5) — instead of ten in one chain on half of the CUs (128 members).
+// Both halves invert and both store the same psi; the accumulators they add to are disjoint.  0: one workgroup per member.
+template <int NN, int HALF = 0>
 __global__ __launch_bounds__(1024) void k_diag_small_reg(SpecDev d, DiagConst c, const double2 *qh, double2 *ph, const double *S, double weight,
                                                          const double *q, const double2 *dq_p, const double2 *dq_pp, DiagAcc acc) {
     double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
@@ -530,7 +534,8 @@ __global__ __launch_bounds__(1024) void k_diag_small_reg(SpecDev d, DiagConst c,
     g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1;
     constexpr int N = NN, NK = NN / 2 + 1, LD = NN + 1, sz = N * NK, rz = N * N;
     constexpr int NPX = (rz + 1023) / 1024, NSP = (sz + 1023) / 1024;
-    const int b = blockIdx.x;
+    const int b = HALF ? blockIdx.x >> 1 : blockIdx.x;
+    const int half = HALF ? 1 + (int)(blockIdx.x & 1) : 0;      // (workgroup-uniform)
     const size_t so = (size_t)b * 2 * sz, ro = (size_t)b * 2 * rz;
     const double2 *qh0 = qh + so, *qh1 = qh + so + sz;
     double u1[NPX], v1[NPX], u2[NPX], v2[NPX];
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(1024) void k_diag_small_reg(SpecDev d, DiagConst c,
         }
     };
     const double2 zero = make_double2(0., 0.);
+    if (half != 2) {
     // ---- p = irfft2(psi): ptpc = p_1 - p_2 is used once, by the first product pair, which goes straight back into the field
     build_psi_pair(false);
     __syncthreads();
@@ -651,6 +657,8 @@ __global__ __launch_bounds__(1024) void k_diag_small_reg(SpecDev d, DiagConst c,
         }
     }
     __syncthreads();
+    }       // half != 2
+    if (half == 1) return;
     // ---- the forcing's spectrum (held in LDS behind the field and its tables: every thread re-reads what it wrote itself),
     //      the enstrophy flux of layer 1 (held in registers), of layer 2, and everything else
     double2 *SH = reinterpret_cast<double2 *>(qgx_smem + diag_reg_side_offset(NN));
@@ -868,7 +876,10 @@ int small_prepare(const SpecDev &d) {
         QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_diag_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         if constexpr (NN == 32 || NN == 48 || NN == 64)
+        {
             QGX_HIP(hipFuncSetAttribute((const void *)k_diag_small_reg<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_reg_lds_bytes(NN)));
+            QGX_HIP(hipFuncSetAttribute((const void *)(k_diag_small_reg<NN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)diag_reg_lds_bytes(NN)));
+        }
         QGX_HIP(hipFuncSetAttribute((const void *)k_diag_inv_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_diag_fwd_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     })
@@ -915,7 +926,17 @@ int small_invert(const SpecDev &d, const ModelOpts &o, const double2 *qh, double
 // ph, u, v.  -> false: no such kernel for this grid
 bool small_diag_increment_reg_ok(const SpecDev &d) { return d.N == 32 || d.N == 48 || d.N == 64; }
 int small_diag_increment_reg(const SpecDev &d, const DiagConst &c, const double2 *qh, double2 *ph, const double *S, double weight, const double *q,
-                             const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st) {
+                             const double2 *dq_p, const double2 *dq_pp, const DiagAcc &a, hipStream_t st, bool halves) {
+    if (halves) {      // two workgroups per member (k_diag_small_reg HALF)
+        switch (d.N) {
+            case 32: hipLaunchKernelGGL((k_diag_small_reg<32, 1>), dim3(2 * d.B), dim3(1024), diag_reg_lds_bytes(32), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
+            case 48: hipLaunchKernelGGL((k_diag_small_reg<48, 1>), dim3(2 * d.B), dim3(1024), diag_reg_lds_bytes(48), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
+            case 64: hipLaunchKernelGGL((k_diag_small_reg<64, 1>), dim3(2 * d.B), dim3(1024), diag_reg_lds_bytes(64), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
+            default: QGX_REQUIRE(false, "small_diag_increment_reg: no kernel for N = %d", d.N);
+        }
+        QGX_HIP(hipGetLastError());
+        return QGX_OK;
+    }
     switch (d.N) {
         case 32: hipLaunchKernelGGL(k_diag_small_reg<32>, dim3(d.B), dim3(1024), diag_reg_lds_bytes(32), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
         case 48: hipLaunchKernelGGL(k_diag_small_reg<48>, dim3(d.B), dim3(1024), diag_reg_lds_bytes(48), st, d, c, qh, ph, S, weight, q, dq_p, dq_pp, a); break;
