@@ -129,7 +129,7 @@ __global__ __launch_bounds__(512) void k_co(int mode, int iters, int prio, float
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
             for (int r = 0; r < 20; ++r) {
-                if (VKIND == 0 || VKIND == 3 || VKIND == 4 || VKIND == 5) {
+                if (VKIND == 0 || VKIND == 3 || VKIND == 4 || VKIND == 5 || VKIND == 6) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(c0), "v"(c1));
                 } else if (VKIND == 1) {
@@ -156,6 +156,12 @@ __global__ __launch_bounds__(512) void k_co(int mode, int iters, int prio, float
 #pragma unroll
                         for (int q = 0; q < 8; ++q) x[q] += gvv[q][0];
                     }
+                }
+                if (VKIND == 6) {
+                    // the same 1-KB wave load straight into LDS (global_load_lds_dwordx4: no VGPR write-back)
+                    const char *gp = reinterpret_cast<const char *>(gbuf) + (((it * 20 + r) & 255) * 4096) + threadIdx.x * 16;
+                    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(gp),
+                                                     (void __attribute__((address_space(3))) *)(&lds[8192 + (wave - 4) * 1024 + (r & 3) * 256]), 16, 0, 0);
                 }
                 if (VKIND == 3 && (r & 3) == 0) {
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(&lds[((threadIdx.x * 4 + r * 64) & 16380)]);
@@ -194,6 +200,9 @@ int main() {
     float *sink; unsigned long long *dt;
     CK(hipMalloc(&sink, 64)); CK(hipMalloc(&dt, 64));
     CK(hipMalloc(&g_gbuf, 2 << 20)); CK(hipMemset(g_gbuf, 0, 2 << 20));
+    if (run<6>("v_fma + 1 global_load_lds / 16", sink, dt)) return 1;
+    if (run<6, 2>("... MFMA pairs + LDS", sink, dt)) return 1;
+    if (run<6, 3>("v_fma+lds-dma; MFMA+LDS+4 loads/24", sink, dt)) return 1;
     if (run<4>("v_fma + 1 global_load / 16 (vaddr)", sink, dt)) return 1;
     if (run<5>("v_fma + 1 global_load / 16 (other lines)", sink, dt)) return 1;
     if (run<4, 2>("... MFMA pairs + LDS", sink, dt)) return 1;
