@@ -136,10 +136,13 @@ int main(int argc, char **argv) {
         run_shape<128, 64, 8>(16, hin, dw, dbias, dscale, dshift, drange, reps);
         run_shape<128, 64, 4>(4, hin, dw, dbias, dscale, dshift, drange, reps);
     }
-#ifdef QGX_W2_STAMPS
+#if defined(QGX_W2_STAMPS) || defined(QGX_W2_EXPS)
     {   // one stamped launch of the headline shape: per phase (id, cycles since the previous stamp) of team A and team B
+        // (-DQGX_W2_EXPS: the timing experiment alone, without the stamps' own cost)
+#ifdef QGX_W2_STAMPS
         unsigned long long *dst; CK(hipMalloc(&dst, 16 * 512 * 8)); CK(hipMemset(dst, 0, 16 * 512 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_w2_stamps), &dst, sizeof(dst)));
+#endif
         const int exp = argc > 3 ? atoi(argv[3]) : 0;
         if (exp == 1) run_shape<64, 64, 8, 1>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 2) run_shape<64, 64, 8, 2>(B, hin, dw, dbias, dscale, dshift, drange, 5);
@@ -157,6 +160,7 @@ int main(int argc, char **argv) {
         else if (exp == 14) run_shape<64, 64, 8, 14>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else if (exp == 15) run_shape<64, 64, 8, 15>(B, hin, dw, dbias, dscale, dshift, drange, 5);
         else run_shape<64, 64, 8>(B, hin, dw, dbias, dscale, dshift, drange, 5);
+#ifdef QGX_W2_STAMPS
         std::vector<unsigned long long> st(16 * 512);
         CK(hipMemcpy(st.data(), dst, st.size() * 8, hipMemcpyDeviceToHost));
         for (int wg = 0; wg < 2; ++wg)
@@ -170,6 +174,7 @@ int main(int argc, char **argv) {
                 }
                 printf("\n");
             }
+#endif
     }
 #endif
     unsigned flags; CK(hipMemcpy(&flags, drange, 4, hipMemcpyDeviceToHost));
