@@ -138,6 +138,22 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     const int sz = N * NK, rz = N * N;
     const double2 *qh0 = a.qh_in + so, *qh1 = qh0 + sz;
     float in_max = 0.f;
+    // Latency chain (one workgroup per CU, nobody to hide a round trip to memory behind): the raw generator output of the
+    // folded output kernel is fetched BEFORE the Philox arithmetic of the next step's noise, the real-space q of the advection
+    // products before the inverse transform in front of them, and the new spectral state goes from the time-step loop to
+    // the last inverse transform in registers.  The arithmetic and its order are untouched.
+    constexpr bool PF = LSPLIT && NN != 0;           // (compile-time sizes, 1024 threads)
+    constexpr int NPXL = PF ? (NN * NN + 1023) / 1024 : 1, NSPL = PF ? (NN * (NN / 2 + 1) + 1023) / 1024 : 1;
+    constexpr bool PFY = PF && NN <= 64;             // (96 x 96: nine pixels per thread leave no registers for it)
+    float yraw[PFY ? 16 : 1];
+    if (PFY && PART != 1 && a.has_S && a.gf.y) {
+        const float *yk = a.gf.y + ((size_t)b * 2 + kown) * rz;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = u * 1024 + (int)threadIdx.x;
+            yraw[u] = i < rz ? yk[i] : 0.f;
+        }
+    }
     if (LSPLIT && PART != 1 && a.gf.X) {
         // next step's latent channel first: it depends on nothing this kernel computes, and here its arithmetic
         // (Philox rounds, log, sincos) runs while the first global loads of the step are in flight
@@ -175,7 +191,8 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
 #pragma unroll
             for (int u = 0; u < KEEP; ++u) {
                 const int i = u * (int)blockDim.x + (int)threadIdx.x;
-                keep[u] = i < rz ? (double)((y1k ? yk[i] + y1k[i] : yk[i]) * ys) : 0.0;
+                if constexpr (PFY) keep[u] = i < rz ? (double)((y1k ? yraw[u] + y1k[i] : yraw[u]) * ys) : 0.0;
+                else keep[u] = i < rz ? (double)((y1k ? yk[i] + y1k[i] : yk[i]) * ys) : 0.0;
                 acc += keep[u];
             }
             double mu = 0.0;
@@ -229,29 +246,51 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
         __syncthreads();
     }
 
+    double2 qnew[NSPL];
     for (int k = kown; k < (LSPLIT ? kown + 1 : 2); ++k) {
         if constexpr (PART != 2) {
             // ---- _invert: ph_k, (u_k, v_k) = irfft2(-il ph, ik ph)
             build_uv(Z, g, d, k, qh0, qh1, a.diag ? a.ph + so + k * sz : nullptr);
+            const double *qk = a.q + ro + k * rz;
+            double qpre[NPXL];
+            if constexpr (PF) {
+#pragma unroll
+                for (int r = 0; r < NPXL; ++r) { const int idx = (int)threadIdx.x + r * 1024; qpre[r] = idx < rz ? qk[idx] : 0.0; }
+            }
             __syncthreads();
             fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
             // ---- _do_advection, real space: uq = (u+U) q, vq = v q
             {
-                const double *qk = a.q + ro + k * rz;
                 const double Uk = d.U[k];
-                for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
-                    const int y = idx / N, x = idx - y * N;
-                    const double2 uv = Z[y * LD + x];
-                    if (a.diag) { a.u[ro + k * rz + idx] = uv.x; a.v[ro + k * rz + idx] = uv.y; }
-                    const double qv = qk[idx];
-                    Z[y * LD + x] = make_double2((uv.x + Uk) * qv, uv.y * qv);
+                if constexpr (PF) {
+#pragma unroll
+                    for (int r = 0; r < NPXL; ++r) {
+                        const int idx = (int)threadIdx.x + r * 1024;
+                        if (idx < rz) {
+                            const int y = idx / N, x = idx - y * N;
+                            const double2 uv = Z[y * LD + x];
+                            if (a.diag) { a.u[ro + k * rz + idx] = uv.x; a.v[ro + k * rz + idx] = uv.y; }
+                            const double qv = qpre[r];
+                            Z[y * LD + x] = make_double2((uv.x + Uk) * qv, uv.y * qv);
+                        }
+                    }
+                } else {
+                    for (int idx = threadIdx.x; idx < rz; idx += blockDim.x) {
+                        const int y = idx / N, x = idx - y * N;
+                        const double2 uv = Z[y * LD + x];
+                        if (a.diag) { a.u[ro + k * rz + idx] = uv.x; a.v[ro + k * rz + idx] = uv.y; }
+                        const double qv = qk[idx];
+                        Z[y * LD + x] = make_double2((uv.x + Uk) * qv, uv.y * qv);
+                    }
                 }
             }
             __syncthreads();
             fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
         }
         // ---- spectral tendency, friction, forcing, AB3 + filter (_forward_timestep)
-        for (int idx = threadIdx.x; idx < sz; idx += blockDim.x) {
+        // (PF: element r of a thread is idx = tid + 1024 r, which is also what this loop visits in its r-th trip)
+        int trip = 0;
+        for (int idx = threadIdx.x; idx < sz; idx += blockDim.x, ++trip) {
             const int j = idx / NK, i = idx - j * NK;
             const size_t o = so + k * sz + idx;
             const double2 q0 = qh0[idx], q1 = qh1[idx];
@@ -286,15 +325,39 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
                 const double2 qk = k == 0 ? q0 : q1;
                 const double f = d.filtr[idx];
                 a.dq_new[o] = make_double2(tx, ty);
-                a.qh_out[o] = make_double2(f * (qk.x + a.dt1 * tx + a.dt2 * p.x + a.dt3 * pp.x),
-                                           f * (qk.y + a.dt1 * ty + a.dt2 * p.y + a.dt3 * pp.y));
+                const double2 qn = make_double2(f * (qk.x + a.dt1 * tx + a.dt2 * p.x + a.dt3 * pp.x),
+                                                f * (qk.y + a.dt1 * ty + a.dt2 * p.y + a.dt3 * pp.y));
+                a.qh_out[o] = qn;
+                if constexpr (PF) {
+#pragma unroll
+                    for (int r = 0; r < NSPL; ++r) if (r == trip) qnew[r] = qn;
+                }
             }
         }
         __syncthreads();
     }
     if constexpr (PART == 1) return;
     // ---- q^{n+1} = irfft2(qh^{n+1}), both layers packed (LSPLIT: the own layer alone)
-    if (LSPLIT) build_pair(Z, g, a.qh_out + so + kown * sz, nullptr, d.invN2);
+    if constexpr (PF) {
+        // build_pair(qh_out_k, nullptr) with the own elements from registers; the mirrors of the two self-conjugate columns
+        // were written by other threads (behind the barrier above)
+        const double2 *Ah = a.qh_out + so + kown * sz;
+#pragma unroll
+        for (int r = 0; r < NSPL; ++r) {
+            const int idx = (int)threadIdx.x + r * 1024;
+            if (idx < sz) {
+                const int j = idx / NK, i = idx - j * NK;
+                double2 av = qnew[r], bv = make_double2(0., 0.);
+                if (i == 0 || 2 * i == N) {
+                    const int idm = neg_mod(j, N) * NK + i;
+                    const double2 am = Ah[idm], bm = make_double2(0., 0.);
+                    av = make_double2(0.5 * (av.x + am.x), 0.5 * (av.y - am.y));
+                    bv = make_double2(0.5 * (bv.x + bm.x), 0.5 * (bv.y - bm.y));
+                }
+                pack_store(Z, g, j, i, av, bv, d.invN2);
+            }
+        }
+    } else if (LSPLIT) build_pair(Z, g, a.qh_out + so + kown * sz, nullptr, d.invN2);
     else build_pair(Z, g, a.qh_out + so, a.qh_out + so + sz, d.invN2);
     __syncthreads();
     fft2d_inv_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
