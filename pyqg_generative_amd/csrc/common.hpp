@@ -59,6 +59,9 @@ struct ModelOpts {
                                  //   (-1: while 6 B <= 256 | 0 | 1)
     int lsplit = -1;             // small grids: two workgroups per member, one per layer (-1 auto | 0 | 1)
     int spec_threads = 0;        // small grids: threads of the one-workgroup-per-member kernels (0 auto | 256 | 512 | 1024)
+    int siblings = -1;           // small grids in layer-split form with a forcing: FOUR workgroups per member — the forcing's transform on a
+                                 //   workgroup of its own beside the inversion / advection chain of its layer, joined by a flag in memory
+                                 //   (-1: up to 8 members, where it measured ahead | 0 | 1: whenever asked, 4 B <= 256 is the caller's business)
     int split_adv = 0;           // small grids in layer-split form + generator: the half of the step kernel that needs nothing of the forcing
                                  //   (inversion, advection, its transform) as a kernel of its own on a side stream, under the generator's
                                  //   layers (0 | 1).  Bit-identical and measured SLOWER almost everywhere (the two cross-stream
@@ -133,6 +136,10 @@ struct StepArgs {
     double weight;
     int has_S, demean, diag;
     GenFuse gf;
+    // k_step_small PART 3 (forcing and advection workgroups of a (member, layer) in one launch): one word per (member, layer),
+    // set to the launch's epoch by the forcing workgroup once the forcing's spectrum is in memory
+    unsigned long long *sib_flag = nullptr;
+    unsigned long long sib_epoch = 0;
 };
 
 // time-averaged diagnostics (diag.hip; the small-grid increment is one kernel of spectral_small.hip)
@@ -206,6 +213,8 @@ struct qgx_model {
     double2 *dg_z = nullptr;               // large grids: the four work fields of the three-launch increment (spectral_large.hip)
     // the two internal streams of a step in halves (model.hip::qgx_step) and their fork / join events
     // side stream and fork / join events of the two-kernel step (model.hip::step_core); a half-ensemble uses set adv_slot
+    unsigned long long *sib_flag = nullptr;      // (B, 2) words of the four-workgroup step, and the epoch of its last launch
+    unsigned long long sib_epoch = 0;
     hipStream_t adv_stream[2] = {nullptr, nullptr};
     hipEvent_t adv_event[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int adv_slot = 0;

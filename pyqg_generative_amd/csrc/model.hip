@@ -64,6 +64,12 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
     if (pre) {
         QGX_HIP(hipStreamWaitEvent(st, m->adv_event[m->adv_slot][1], 0));
         rc = small_step(m->d, m->opts, a, st, 2);
+    } else if (m->small && has_S && m->sib_flag && m->opts.siblings != 0 && small_layer_split(m->d, m->opts) &&
+               (m->opts.siblings == 1 || m->B <= 8)) {          // measured: ahead up to 8 members (bench_tools/steptime.py)
+        // the forcing's transform on a workgroup of its own beside the inversion / advection chain (k_step_small PART 3)
+        a.sib_flag = m->sib_flag;
+        a.sib_epoch = ++m->sib_epoch;
+        rc = small_step(m->d, m->opts, a, st, 3);
     } else {
         rc = m->small ? small_step(m->d, m->opts, a, st) : large_step(m, a, st);
     }
@@ -326,6 +332,7 @@ extern "C" int qgx_destroy(qgx_model *m) {
     for (double *p : m->dg_R) if (p) (void)hipFree(p);
     for (double *p : m->dg_S) if (p) (void)hipFree(p);
     for (double *p : m->dg_acc) if (p) (void)hipFree(p);
+    if (m->sib_flag) (void)hipFree(m->sib_flag);
     for (hipStream_t sst : m->adv_stream) if (sst) (void)hipStreamDestroy(sst);
     for (auto &evs : m->adv_event) for (hipEvent_t ev : evs) if (ev) (void)hipEventDestroy(ev);
     for (hipStream_t sst : m->sub_stream) if (sst) (void)hipStreamDestroy(sst);
@@ -432,6 +439,7 @@ extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
     else if (!strcmp(name, "diag_wide")) { QGX_REQUIRE(value >= -1 && value <= 1, "diag_wide must be -1 (auto), 0 or 1"); o.diag_wide = value; }
     else if (!strcmp(name, "diag_reg")) { QGX_REQUIRE(value >= 0 && value <= 3, "diag_reg must be 0, 1 (auto), 2 (one workgroup per member) or 3 (two)"); o.diag_reg = value; }
     else if (!strcmp(name, "lsplit")) { QGX_REQUIRE(value >= -1 && value <= 1, "lsplit must be -1 (auto), 0 or 1"); o.lsplit = value; }
+    else if (!strcmp(name, "siblings")) { QGX_REQUIRE(value >= -1 && value <= 1, "siblings must be -1 (auto), 0 or 1"); o.siblings = value; }
     else if (!strcmp(name, "split_adv")) { QGX_REQUIRE(value == 0 || value == 1, "split_adv must be 0 or 1"); o.split_adv = value; }
     else if (!strcmp(name, "streams")) { QGX_REQUIRE(value >= 0 && value <= 2, "streams must be 0 (auto), 1 or 2"); o.streams = value; }
     else if (!strcmp(name, "spec_threads")) {
@@ -495,6 +503,12 @@ extern "C" int qgx_status_ke_cfl(qgx_model *m, double *out_dev, void *stream) {
 static bool step_adv_applies(const qgx_model *m) {
     if (m->plan_only || !m->small || m->opts.split_adv == 0 || !small_layer_split(m->d, m->opts) || !m->adv_stream[m->adv_slot]) return false;
     return m->opts.split_adv == 1;
+}
+static int step_sib_ensure(qgx_model *m) {
+    if (!m->small || m->opts.siblings == 0 || m->sib_flag || m->plan_only) return QGX_OK;
+    QGX_HIP(hipMalloc((void **)&m->sib_flag, (size_t)2 * m->B * sizeof(unsigned long long)));
+    QGX_HIP(hipMemset(m->sib_flag, 0, (size_t)2 * m->B * sizeof(unsigned long long)));
+    return QGX_OK;
 }
 static int step_adv_ensure(qgx_model *m) {
     if (!m->small || m->opts.split_adv == 0) return QGX_OK;
@@ -682,6 +696,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
     hipStream_t st = (hipStream_t)stream;
     { int trc = team_settle(m, st); if (trc) return trc; }
     if (p && p->gen && nsteps > 0) { int arc = step_adv_ensure(m); if (arc) return arc; }
+    if (p && (p->gen || p->forcing_dev) && nsteps > 0) { int src = step_sib_ensure(m); if (src) return src; }
     if (nsteps == 0 || !step_in_halves(m, p)) {
         if (p && p->gen) { int wrc = generator_select_workspace(p->gen, 0); if (wrc) return wrc; }
         return step_core(m, nsteps, p, refresh_diag, st);
@@ -719,6 +734,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         }
         k.sub_stream[0] = k.sub_stream[1] = nullptr;
         k.adv_slot = c;
+        if (k.sib_flag) k.sib_flag += b0 * 2;
         pp[c].member_offset = p->member_offset + b0;
     }
     // the halves take turns in chunks of steps (a chunk keeps the fused input / output kernels of consecutive steps fused and
@@ -772,6 +788,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
     m->tc = k.tc; m->ablevel = k.ablevel; m->cur_q = k.cur_q; m->i_new = k.i_new; m->i_p = k.i_p; m->i_pp = k.i_pp; m->i_x = k.i_x;
     m->z_double = k.z_double; m->have_noise = k.have_noise; m->const_counter = k.const_counter; m->have_forcing = k.have_forcing;
     m->noise_step = k.noise_step; m->uv_stale = k.uv_stale; m->q_stale = k.q_stale; m->dg_count = k.dg_count;
+    m->sib_epoch = k.sib_epoch > child[1].sib_epoch ? k.sib_epoch : child[1].sib_epoch;
     m->x_ready_gen = nullptr;
     return QGX_OK;
 }

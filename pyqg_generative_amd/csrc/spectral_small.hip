@@ -127,13 +127,22 @@ extern __shared__ __attribute__((aligned(16))) char qgx_smem[];
 template <int NN, bool LSPLIT = false, int PART = 0>
 __global__ void k_step_small(SpecDev d, StepArgs a) {
     static_assert(PART == 0 || LSPLIT, "the two-kernel step exists in layer-split form only");
+    // PART 3: both halves in ONE launch of 4 B workgroups.  Blocks [0, 2 B) transform the forcing of their (member, layer),
+    // publish it (agent-scope release: fence by every thread, barrier, flag) and leave; blocks [2 B, 4 B) run the
+    // inversion / advection chain meanwhile and wait for the flag (acquire) in front of the time-step loop: three transforms
+    // in the chain instead of four.  Used while all 4 B workgroups are resident at once (one per CU), so nobody waits for a
+    // workgroup that has no CU; the wait is bounded all the same, and a timed-out step poisons its state (NaN: loud).
+    constexpr bool SIB = PART == 3;
+    const bool roleF = SIB && blockIdx.x < 2u * (unsigned)d.B;
+    const unsigned bid = SIB && !roleF ? blockIdx.x - 2u * (unsigned)d.B : blockIdx.x;
+    const bool fside = PART != 1 && (!SIB || roleF);     // this workgroup does the forcing side (noise, output kernel, forcing transform)
     double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
     int *pos_lds;
     Grid g = make_grid(d, Z, pos_lds);
     if (NN) { g.N = NN; g.NK = NN / 2 + 1; g.LD = NN + 1; }
     const int N = NN ? NN : d.N, NK = NN ? NN / 2 + 1 : d.NK, LD = NN ? NN + 1 : d.LD;
-    const int b = LSPLIT ? blockIdx.x >> 1 : blockIdx.x;
-    const int kown = LSPLIT ? blockIdx.x & 1 : 0;
+    const int b = LSPLIT ? (int)(bid >> 1) : (int)blockIdx.x;
+    const int kown = LSPLIT ? (int)(bid & 1) : 0;
     const size_t so = (size_t)b * 2 * N * NK, ro = (size_t)b * 2 * N * N;
     const int sz = N * NK, rz = N * N;
     const double2 *qh0 = a.qh_in + so, *qh1 = qh0 + sz;
@@ -146,7 +155,7 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     constexpr int NPXL = PF ? (NN * NN + 1023) / 1024 : 1, NSPL = PF ? (NN * (NN / 2 + 1) + 1023) / 1024 : 1;
     constexpr bool PFY = PF && NN <= 64;             // (96 x 96: nine pixels per thread leave no registers for it)
     float yraw[PFY ? 16 : 1];
-    if (PFY && PART != 1 && a.has_S && a.gf.y) {
+    if (PFY && fside && a.has_S && a.gf.y) {
         const float *yk = a.gf.y + ((size_t)b * 2 + kown) * rz;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -154,7 +163,7 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
             yraw[u] = i < rz ? yk[i] : 0.f;
         }
     }
-    if (LSPLIT && PART != 1 && a.gf.X) {
+    if (LSPLIT && fside && a.gf.X) {
         // next step's latent channel first: it depends on nothing this kernel computes, and here its arithmetic
         // (Philox rounds, log, sincos) runs while the first global loads of the step are in flight
         // latent channel kown: z = b * xi, white in time (k_prep_noise with a == 0; quads of the flat (2, N*N) field)
@@ -175,7 +184,7 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     __syncthreads();
 
     // ---- subgrid forcing: Sh_k = rfft2(weight * S_k), pair packed (pyqg _do_q_subgrid_parameterization)
-    if (PART != 1 && a.has_S) {
+    if (fside && a.has_S) {
         const double *S0 = a.S + ro, *S1 = S0 + rz;
         if (LSPLIT && a.gf.y) {
             // the generator's output kernel folded in (k_finish<FIN_PLAIN>, conv.hip: same arithmetic, same summation order —
@@ -246,6 +255,20 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
         __syncthreads();
     }
 
+    if (SIB && roleF) {
+        // the forcing side is done: largest |latent noise| for the range guard, then publish
+        if (a.gf.X) {
+            for (int o = 32; o > 0; o >>= 1) in_max = fmaxf(in_max, __shfl_down(in_max, o));
+            if ((threadIdx.x & 63) == 0 && __float_as_uint(in_max) > __builtin_nontemporal_load(a.gf.range + 1))
+                atomicMax(a.gf.range + 1, __float_as_uint(in_max));
+        }
+        __threadfence();                                     // every thread's stores (dqh, S, z, X) visible device-wide ...
+        __syncthreads();
+        if (threadIdx.x == 0)                                // ... before the flag is
+            __hip_atomic_store(a.sib_flag + bid, a.sib_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    bool sib_lost = false;
     double2 qnew[NSPL];
     for (int k = kown; k < (LSPLIT ? kown + 1 : 2); ++k) {
         if constexpr (PART != 2) {
@@ -287,6 +310,21 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
             __syncthreads();
             fft2d_fwd_x<NN>(Z, N, LD, g.nrad, g.rad, g.tw);
         }
+        if (SIB && a.has_S) {
+            // the forcing's spectrum comes from the sibling workgroup
+            __shared__ int sib_ok;
+            if (threadIdx.x == 0) {
+                int spins = 0, ok = 1;
+                while (__hip_atomic_load(a.sib_flag + bid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.sib_epoch) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1 << 23)) { ok = 0; break; }
+                }
+                sib_ok = ok;
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every wave: no stale line of dqh from its own caches
+            sib_lost = sib_ok == 0;
+        }
         // ---- spectral tendency, friction, forcing, AB3 + filter (_forward_timestep)
         // (PF: element r of a thread is idx = tid + 1024 r, which is also what this loop visits in its r-th trip)
         int trip = 0;
@@ -325,8 +363,9 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
                 const double2 qk = k == 0 ? q0 : q1;
                 const double f = d.filtr[idx];
                 a.dq_new[o] = make_double2(tx, ty);
-                const double2 qn = make_double2(f * (qk.x + a.dt1 * tx + a.dt2 * p.x + a.dt3 * pp.x),
-                                                f * (qk.y + a.dt1 * ty + a.dt2 * p.y + a.dt3 * pp.y));
+                double2 qn = make_double2(f * (qk.x + a.dt1 * tx + a.dt2 * p.x + a.dt3 * pp.x),
+                                          f * (qk.y + a.dt1 * ty + a.dt2 * p.y + a.dt3 * pp.y));
+                if (SIB && sib_lost) qn = make_double2(__longlong_as_double(0x7ff8000000000000ll), 0.);   // never a silently wrong state
                 a.qh_out[o] = qn;
                 if constexpr (PF) {
 #pragma unroll
@@ -934,6 +973,7 @@ int small_prepare(const SpecDev &d) {
         QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        QGX_HIP(hipFuncSetAttribute((const void *)(k_step_small<NN, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_q_to_qh_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_qh_to_q_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         QGX_HIP(hipFuncSetAttribute((const void *)k_invert_small<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -955,13 +995,16 @@ bool small_layer_split(const SpecDev &d, const ModelOpts &o) {
     return 2 * d.B <= 256;      // one workgroup per CU (measured at 64x64: B = 128 44 -> 33 us, B = 256 55 -> 63 us)
 }
 
-// part: 0 the whole step; 1 / 2 its two halves (layer-split form only; k_step_small PART)
+// part: 0 the whole step; 1 / 2 its two halves; 3 both in one launch of 4 B workgroups (layer-split form only; k_step_small PART)
 int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStream_t st, int part) {
     QGX_REQUIRE(part == 0 || small_layer_split(d, o), "small_step: the two-kernel step needs the layer-split form");
     if (part == 1) {
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 1>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else if (part == 2) {
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 2>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
+    } else if (part == 3) {
+        QGX_REQUIRE(a.sib_flag && a.sib_epoch, "small_step: the four-workgroup step needs its flag words");
+        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 3>), dim3(4 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else if (small_layer_split(d, o)) {
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else {

@@ -414,7 +414,8 @@ def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B
     # default / separate generator kernels / one launch per transform / the increment's transforms as (member, transform)
     # workgroups (three launches) / as ONE workgroup per member with its work fields in registers (k_diag_small_reg, grids up to
     # 64 x 64: a quarter of the bytes) / ... with them in global memory (k_diag_small)
-    for opts in ({}, dict(genfuse=0), dict(diag_fused=0), dict(diag_wide=1), dict(diag_wide=0), dict(diag_wide=0, diag_reg=0),
+    # ... / the forcing's transform inside the layer's one workgroup instead of on a sibling workgroup (k_step_small PART 3)
+    for opts in ({}, dict(genfuse=0), dict(siblings=0), dict(siblings=0, genfuse=0), dict(diag_fused=0), dict(diag_wide=1), dict(diag_wide=0), dict(diag_wide=0, diag_reg=0),
                  dict(diag_wide=0, diag_reg=2), dict(diag_wide=0, diag_reg=3)):
         e = _engine(N, B, dt=dt_for(N))
         for opt, val in opts.items():
@@ -442,7 +443,7 @@ def test_step_kernel_as_two_kernels_on_two_streams_changes_nothing(kind, N, B, s
     q0 = _eddy_like_q(np.random.RandomState(9), B, N)
     gen = _gpu_generator(kind)
     res = []
-    for opts in ({}, dict(split_adv=1), dict(split_adv=1, genfuse=0), dict(streams=2), dict(split_adv=1, streams=2)):
+    for opts in ({}, dict(split_adv=1), dict(split_adv=1, genfuse=0), dict(streams=2), dict(split_adv=1, streams=2), dict(siblings=0), dict(siblings=0, streams=2)):
         e = _engine(N, B, dt=dt_for(N))
         for opt, val in opts.items():
             e.set_option(opt, val)
@@ -452,7 +453,7 @@ def test_step_kernel_as_two_kernels_on_two_streams_changes_nothing(kind, N, B, s
             e.step(chunk, generator=gen, sampling=sampling, nsteps_decor=nd, seed=11, member_offset=3)
         res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Z, L.F_Q, L.F_U, L.F_PH)] + [e.diag(n).clone() for n in _lib_diags()])
         e.close()
-    for ref, other in ((0, 1), (0, 2), (3, 4)):      # (the halves against the halves: they may take other generator kernels than the whole)
+    for ref, other in ((0, 1), (0, 2), (3, 4), (0, 5), (3, 6)):      # (the halves against the halves: they may take other generator kernels than the whole)
         for a, b in zip(res[ref], res[other]):
             assert torch.equal(a, b)
 
