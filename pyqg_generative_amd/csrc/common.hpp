@@ -61,7 +61,8 @@ struct ModelOpts {
     int spec_threads = 0;        // small grids: threads of the one-workgroup-per-member kernels (0 auto | 256 | 512 | 1024)
     int siblings = -1;           // small grids in layer-split form with a forcing: FOUR workgroups per member — the forcing's transform on a
                                  //   workgroup of its own beside the inversion / advection chain of its layer, joined by a flag in memory
-                                 //   (-1: up to 8 members, where it measured ahead | 0 | 1: whenever asked, 4 B <= 256 is the caller's business)
+                                 //   (-1: while 4 B <= 256, i.e. all of them resident at once: +2 ... +9 % of the online step | 0 | 1 |
+                                 //   2: as 1, always with the cross-XCD publication — the path siblings on different XCDs take)
     int split_adv = 0;           // small grids in layer-split form + generator: the half of the step kernel that needs nothing of the forcing
                                  //   (inversion, advection, its transform) as a kernel of its own on a side stream, under the generator's
                                  //   layers (0 | 1).  Bit-identical and measured SLOWER almost everywhere (the two cross-stream
@@ -140,6 +141,7 @@ struct StepArgs {
     // set to the launch's epoch by the forcing workgroup once the forcing's spectrum is in memory
     unsigned long long *sib_flag = nullptr;
     unsigned long long sib_epoch = 0;
+    int sib_full = 0;           // publish across XCDs even to a sibling on the same one (option siblings = 2: exercises that path)
 };
 
 // time-averaged diagnostics (diag.hip; the small-grid increment is one kernel of spectral_small.hip)

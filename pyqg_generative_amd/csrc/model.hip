@@ -65,10 +65,11 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
         QGX_HIP(hipStreamWaitEvent(st, m->adv_event[m->adv_slot][1], 0));
         rc = small_step(m->d, m->opts, a, st, 2);
     } else if (m->small && has_S && m->sib_flag && m->opts.siblings != 0 && small_layer_split(m->d, m->opts) &&
-               (m->opts.siblings == 1 || m->B <= 8)) {          // measured: ahead up to 8 members (bench_tools/steptime.py)
+               (m->opts.siblings >= 1 || 4 * m->B <= 256)) {    // while all four workgroups of every member are resident at once
         // the forcing's transform on a workgroup of its own beside the inversion / advection chain (k_step_small PART 3)
         a.sib_flag = m->sib_flag;
         a.sib_epoch = ++m->sib_epoch;
+        a.sib_full = m->opts.siblings == 2;
         rc = small_step(m->d, m->opts, a, st, 3);
     } else {
         rc = m->small ? small_step(m->d, m->opts, a, st) : large_step(m, a, st);
@@ -439,7 +440,7 @@ extern "C" int qgx_set_option(qgx_model *m, const char *name, int value) {
     else if (!strcmp(name, "diag_wide")) { QGX_REQUIRE(value >= -1 && value <= 1, "diag_wide must be -1 (auto), 0 or 1"); o.diag_wide = value; }
     else if (!strcmp(name, "diag_reg")) { QGX_REQUIRE(value >= 0 && value <= 3, "diag_reg must be 0, 1 (auto), 2 (one workgroup per member) or 3 (two)"); o.diag_reg = value; }
     else if (!strcmp(name, "lsplit")) { QGX_REQUIRE(value >= -1 && value <= 1, "lsplit must be -1 (auto), 0 or 1"); o.lsplit = value; }
-    else if (!strcmp(name, "siblings")) { QGX_REQUIRE(value >= -1 && value <= 1, "siblings must be -1 (auto), 0 or 1"); o.siblings = value; }
+    else if (!strcmp(name, "siblings")) { QGX_REQUIRE(value >= -1 && value <= 2, "siblings must be -1 (auto), 0, 1 or 2"); o.siblings = value; }
     else if (!strcmp(name, "split_adv")) { QGX_REQUIRE(value == 0 || value == 1, "split_adv must be 0 or 1"); o.split_adv = value; }
     else if (!strcmp(name, "streams")) { QGX_REQUIRE(value >= 0 && value <= 2, "streams must be 0 (auto), 1 or 2"); o.streams = value; }
     else if (!strcmp(name, "spec_threads")) {
@@ -506,8 +507,9 @@ static bool step_adv_applies(const qgx_model *m) {
 }
 static int step_sib_ensure(qgx_model *m) {
     if (!m->small || m->opts.siblings == 0 || m->sib_flag || m->plan_only) return QGX_OK;
-    QGX_HIP(hipMalloc((void **)&m->sib_flag, (size_t)2 * m->B * sizeof(unsigned long long)));
-    QGX_HIP(hipMemset(m->sib_flag, 0, (size_t)2 * m->B * sizeof(unsigned long long)));
+    // [0, 2 B): the forcing workgroups' flags; [2 B, 4 B): where the chain workgroups run
+    QGX_HIP(hipMalloc((void **)&m->sib_flag, (size_t)4 * m->B * sizeof(unsigned long long)));
+    QGX_HIP(hipMemset(m->sib_flag, 0, (size_t)4 * m->B * sizeof(unsigned long long)));
     return QGX_OK;
 }
 static int step_adv_ensure(qgx_model *m) {
@@ -734,7 +736,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         }
         k.sub_stream[0] = k.sub_stream[1] = nullptr;
         k.adv_slot = c;
-        if (k.sib_flag) k.sib_flag += b0 * 2;
+        if (k.sib_flag) k.sib_flag += b0 * 4;          // (a half owns the flag words and the placement words of its members: 4 per member)
         pp[c].member_offset = p->member_offset + b0;
     }
     // the halves take turns in chunks of steps (a chunk keeps the fused input / output kernels of consecutive steps fused and

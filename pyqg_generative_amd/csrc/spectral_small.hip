@@ -134,7 +134,14 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
     // workgroup that has no CU; the wait is bounded all the same, and a timed-out step poisons its state (NaN: loud).
     constexpr bool SIB = PART == 3;
     const bool roleF = SIB && blockIdx.x < 2u * (unsigned)d.B;
-    const unsigned bid = SIB && !roleF ? blockIdx.x - 2u * (unsigned)d.B : blockIdx.x;
+    // the chain workgroups start at a multiple of 8, so that (workgroups being dealt to the 8 XCDs round-robin) a pair of
+    // siblings shares an XCD and its L2 — checked at run time, see below; the blocks in between have nothing to do
+    const unsigned m0 = (2u * (unsigned)d.B + 7u) & ~7u;
+    if (SIB && !roleF && blockIdx.x < m0) return;
+    const unsigned bid = SIB && !roleF ? blockIdx.x - m0 : blockIdx.x;
+    const unsigned my_xcc = SIB ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u) : 0u;     // HW_REG_XCC_ID
+    if (SIB && !roleF && threadIdx.x == 0)      // where the chain workgroup runs, tagged with the launch's epoch
+        __hip_atomic_store(a.sib_flag + 2 * (size_t)d.B + bid, (a.sib_epoch << 4) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool fside = PART != 1 && (!SIB || roleF);     // this workgroup does the forcing side (noise, output kernel, forcing transform)
     double2 *Z = reinterpret_cast<double2 *>(qgx_smem);
     int *pos_lds;
@@ -262,10 +269,21 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
             if ((threadIdx.x & 63) == 0 && __float_as_uint(in_max) > __builtin_nontemporal_load(a.gf.range + 1))
                 atomicMax(a.gf.range + 1, __float_as_uint(in_max));
         }
-        __threadfence();                                     // every thread's stores (dqh, S, z, X) visible device-wide ...
+        // Same XCD as the sibling (it said so for THIS launch): both ends share one L2, so it is enough that every wave's
+        // stores have left the CU (write-through L1, vmcnt drained) before the flag goes to that L2 — the exchange of
+        // spectral_large.hip's team barrier.  Otherwise (another XCD, or the sibling has not started yet): agent-scope
+        // release, i.e. the L2's dirty lines written back, and the flag tells the sibling to invalidate on its side.
+        __shared__ int sib_same;
+        if (threadIdx.x == 0)
+            sib_same = __hip_atomic_load(a.sib_flag + 2 * (size_t)d.B + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ((a.sib_epoch << 4) | my_xcc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0)                                // ... before the flag is
-            __hip_atomic_store(a.sib_flag + bid, a.sib_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const bool same = sib_same != 0 && !a.sib_full;
+        if (!same) { __threadfence(); __syncthreads(); }
+        if (threadIdx.x == 0) {
+            if (same) __hip_atomic_store(a.sib_flag + bid, a.sib_epoch << 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else __hip_atomic_store(a.sib_flag + bid, (a.sib_epoch << 1) | 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
         return;
     }
     bool sib_lost = false;
@@ -314,15 +332,19 @@ __global__ void k_step_small(SpecDev d, StepArgs a) {
             // the forcing's spectrum comes from the sibling workgroup
             __shared__ int sib_ok;
             if (threadIdx.x == 0) {
-                int spins = 0, ok = 1;
-                while (__hip_atomic_load(a.sib_flag + bid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.sib_epoch) {
+                int spins = 0, ok = 0;
+                for (;;) {
+                    const unsigned long long f = __hip_atomic_load(a.sib_flag + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((f >> 1) == a.sib_epoch) { ok = 1 + (int)(f & 1ull); break; }
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1 << 23)) { ok = 0; break; }
+                    if (++spins > (1 << 23)) break;
                 }
                 sib_ok = ok;
             }
             __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every wave: no stale line of dqh from its own caches
+            // 2: published across XCDs — every wave invalidates (agent-scope acquire); 1: the sibling shares this L2 and this
+            // CU's L1 holds no line of dqh yet (never read in this launch): nothing to do
+            if (sib_ok == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             sib_lost = sib_ok == 0;
         }
         // ---- spectral tendency, friction, forcing, AB3 + filter (_forward_timestep)
@@ -1004,7 +1026,7 @@ int small_step(const SpecDev &d, const ModelOpts &o, const StepArgs &a, hipStrea
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 2>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else if (part == 3) {
         QGX_REQUIRE(a.sib_flag && a.sib_epoch, "small_step: the four-workgroup step needs its flag words");
-        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 3>), dim3(4 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
+        QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true, 3>), dim3(((2 * d.B + 7) & ~7) + 2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else if (small_layer_split(d, o)) {
         QGX_DISPATCH_N(d.N, hipLaunchKernelGGL((k_step_small<NN, true>), dim3(2 * d.B), dim3(1024), small_lds_bytes(d), st, d, a))
     } else {

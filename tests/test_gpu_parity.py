@@ -415,7 +415,8 @@ def test_generator_kernels_folded_into_the_step_kernel_change_nothing(kind, N, B
     # workgroups (three launches) / as ONE workgroup per member with its work fields in registers (k_diag_small_reg, grids up to
     # 64 x 64: a quarter of the bytes) / ... with them in global memory (k_diag_small)
     # ... / the forcing's transform inside the layer's one workgroup instead of on a sibling workgroup (k_step_small PART 3)
-    for opts in ({}, dict(genfuse=0), dict(siblings=0), dict(siblings=0, genfuse=0), dict(diag_fused=0), dict(diag_wide=1), dict(diag_wide=0), dict(diag_wide=0, diag_reg=0),
+    # (siblings = 2: with the cross-XCD publication, the path a pair placed on two XCDs takes)
+    for opts in ({}, dict(genfuse=0), dict(siblings=0), dict(siblings=0, genfuse=0), dict(siblings=2), dict(diag_fused=0), dict(diag_wide=1), dict(diag_wide=0), dict(diag_wide=0, diag_reg=0),
                  dict(diag_wide=0, diag_reg=2), dict(diag_wide=0, diag_reg=3)):
         e = _engine(N, B, dt=dt_for(N))
         for opt, val in opts.items():
