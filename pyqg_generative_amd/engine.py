@@ -242,11 +242,18 @@ class EnsembleEngine:
     def _spec(self):
         return torch.empty((self.B, 2, self.N, self.NK), dtype=torch.complex128, device=self.device)
 
-    def get(self, field, noise_dtype=torch.float32):
+    def get(self, field, noise_dtype=None):
+        """copy of a state field.  F_Z (the latent noise) has the element type of the generator last stepped with — float32
+        for GAN / VAE, float64 for GZ — which the library reports (qgx_field_bytes); a `noise_dtype` that contradicts it is
+        refused rather than handed a buffer of the wrong size"""
         if field in (_lib.F_Q, _lib.F_U, _lib.F_V, _lib.F_S, _lib.F_P):
             out = self._real()
         elif field == _lib.F_Z:
-            out = torch.empty((self.B, 2, self.N, self.N), dtype=noise_dtype, device=self.device)
+            nbytes = int(lib.qgx_field_bytes(self._h, field))
+            dtype = torch.float64 if nbytes == self.B * 2 * self.N * self.N * 8 else torch.float32
+            if noise_dtype is not None and noise_dtype != dtype:
+                raise ValueError(f'the latent noise of this model is {dtype}, not {noise_dtype}')
+            out = torch.empty((self.B, 2, self.N, self.N), dtype=dtype, device=self.device)
         else:
             out = self._spec()
         check(lib.qgx_get(self._h, field, _ptr(out), _stream()))

@@ -282,6 +282,36 @@ def test_parameterized_diagnostics_with_many_members():
             assert np.abs(got[b] - ref).max() <= tol * np.abs(ref).max(), (name, b)
 
 
+@pytest.mark.parametrize('kind,N,B', [('gan', 64, 100), ('vae', 96, 40), ('gz', 32, 150)])
+def test_four_workgroups_per_member_beyond_residency_are_the_same_step(kind, N, B):
+    """Option `siblings` (k_step_small PART 3): the forcing's transform on a sibling workgroup, joined with its layer's
+    inversion / advection chain by a flag in memory.  The automatic choice keeps all 4 B workgroups resident (4 B <= 256);
+    forced beyond that — 400, 160 and 600 workgroups here, some of them waiting for a CU — the forcing blocks still come first
+    in dispatch order and wait for nothing, so the step completes, bit-identical to the two-workgroup form, through the
+    same-XCD publication (1) and through the cross-XCD one (2); time-averaged diagnostics included."""
+    import pyqg_generative_amd._lib as L
+    gen = _gpu_generator(kind)
+    q0 = _eddy_like_q(np.random.RandomState(B), B, N)
+    res = []
+    for sib in (0, 1, 2):
+        e = _engine(N, B, **(JET if N == 96 else dict(dt=14400. * 64 / N)))
+        e.set_option('siblings', sib)
+        e.set_q(q0)
+        e.diag_config(0, 3)
+        for chunk in (5, 1, 4):
+            e.step(chunk, generator=gen, sampling='AR1', nsteps_decor=2, seed=5, member_offset=1)
+        res.append([e.get(f).clone() for f in (L.F_QH, L.F_S, L.F_Q, L.F_DQHDT, L.F_Z)] + [e.diag(n).clone() for n in ('KEspec', 'paramspec', 'ENSflux')])
+        # the latent noise comes back in the element type of the generator (GZ: float64), a contradicting request is refused
+        assert res[-1][4].dtype == gen.noise_dtype
+        with pytest.raises(ValueError):
+            e.get(L.F_Z, noise_dtype=torch.float32 if kind == 'gz' else torch.float64)
+        e.close()
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.equal(a, b)
+    assert bool(torch.isfinite(res[0][2]).all())
+
+
 def test_an_ensemble_stepped_as_two_halves_on_two_streams_is_the_same_ensemble():
     """qgx_step advances a 96 x 96 ensemble of 16 ... 64 members as two halves on two internal streams (option `streams`:
     0 automatic, 1 never, 2 whenever even; qgx_step_streams): a half is the same model over a slice of the member-major arrays,
