@@ -868,6 +868,7 @@ struct qgx_generator {
     int opt_last_rows = 0;         // VALU last layer: rows per workgroup (0 = automatic)
     int opt_h3 = 0;                // 5x5 layer on 16x16x32 MFMAs (k_convh3): measured no faster in the full kernel
     int opt_half_min_tiles = 1;
+    int opt_tiny_pairs = 7;        // tiny ensembles at 64 x 64 (split-K path): bit 0 layers (7, 8), bit 1 layers (5, 6), bit 2 layers (3, 4) as ONE fused launch on 2-row strips
     int opt_pair_lp = 1;           // A/B library only: 0 = the pair kernels fetch the two halves of a line in different chunk iterations
     int opt_small_tiles = 1;       // 64 x 64, at most 4 members: half-height tiles (small_tiles())
     int opt_fuse96 = 2;            // ... at 96 x 96 (4-row strips): bit 0 (5,6), 1 (7,8)
@@ -2066,14 +2067,34 @@ static int cnn_forward_half(qgx_generator *g, const NetHost &net, const float *x
         if (g->opt_stop_layer == 2) return QGX_OK;
 #endif
         if (tiny) {
-            bool done2 = false;
-            if ((rc = launch_convh2_part<64, 32, 3, false>(g, 2, net.L[2], Bb, A, Bc, N, st, done2))) return rc;
-            if (!done2 && (rc = conv3x3_half<64, 32, NS, false>(g, 2, net.L[2], Bb, A, Bc, N, st))) return rc;
-            if ((rc = conv3x3_half<32, 32, NS, false>(g, 3, net.L[3], A, Bb, Bc, N, st))) return rc;
-            if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], Bb, A, Bc, N, st))) return rc;
-            if ((rc = conv3x3_half<32, 32, NS, false>(g, 5, net.L[5], A, Bb, Bc, N, st))) return rc;
-            if ((rc = conv3x3_half<32, 32, NS, true>(g, 6, net.L[6], Bb, A, Bc, N, st))) return rc;
-            if ((rc = launch_conv_last(g, net.L[7], A, yc, Bc, N, net.n_out, st))) return rc;
+            // (local names: the 64-channel activation of layer 2 is in Bb; `cur` holds a layer's input, `oth` takes its output)
+            float *cur = Bb, *oth = A;
+            // Layers (3, 4), (5, 6) and (7, 8) each as ONE launch on 2-row strips ("tiny_pairs" bits 2, 1, 0): a single member is
+            // a chain of launch latencies, and a strip's fixed costs — layer B's 36 KB of MFMA weights above all — are cheaper
+            // than a kernel boundary there; for (3, 4) the one launch also replaces split-K and its combine kernel
+            const bool strips = NS == 2 && N == 64 && net.n_out <= 2;
+            if (strips && (g->opt_tiny_pairs & 4)) {
+                if ((rc = launch_convh_pair<64, false, false, 64, 2>(g, 2, net.L[2], net.L[3], cur, oth, Bc, N, 0, st))) return rc;
+                std::swap(cur, oth);
+            } else {
+                bool done2 = false;
+                if ((rc = launch_convh2_part<64, 32, 3, false>(g, 2, net.L[2], cur, oth, Bc, N, st, done2))) return rc;
+                if (!done2 && (rc = conv3x3_half<64, 32, NS, false>(g, 2, net.L[2], cur, oth, Bc, N, st))) return rc;
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 3, net.L[3], oth, cur, Bc, N, st))) return rc;
+            }
+            if (strips && (g->opt_tiny_pairs & 2)) {
+                if ((rc = launch_convh_pair<32, false, false, 64, 2>(g, 4, net.L[4], net.L[5], cur, oth, Bc, N, 0, st))) return rc;
+                std::swap(cur, oth);
+            } else {
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 4, net.L[4], cur, oth, Bc, N, st))) return rc;
+                if ((rc = conv3x3_half<32, 32, NS, false>(g, 5, net.L[5], oth, cur, Bc, N, st))) return rc;
+            }
+            if (strips && (g->opt_tiny_pairs & 1)) {
+                if ((rc = launch_convh_pair<32, true, false, 64, 2>(g, 6, net.L[6], net.L[7], cur, yc, Bc, N, net.n_out, st))) return rc;
+                continue;
+            }
+            if ((rc = conv3x3_half<32, 32, NS, true>(g, 6, net.L[6], cur, oth, Bc, N, st))) return rc;
+            if ((rc = launch_conv_last(g, net.L[7], oth, yc, Bc, N, net.n_out, st))) return rc;
             continue;
         }
         if (NS == 2 && g->opt_fuse && N == 64 && net.n_out <= 2) {
@@ -2613,6 +2634,7 @@ extern "C" int qgx_generator_set_option(qgx_generator *g, const char *name, int 
     else if (!strcmp(name, "fuse")) g->opt_fuse = value & 7;
     else if (!strcmp(name, "fuse96")) g->opt_fuse96 = value & 3;
     else if (!strcmp(name, "small_tiles")) g->opt_small_tiles = value ? 1 : 0;
+    else if (!strcmp(name, "tiny_pairs")) { QGX_REQUIRE(value >= 0 && value <= 7, "tiny_pairs: bits 0 (layers 7, 8), 1 (layers 5, 6), 2 (layers 3, 4)"); g->opt_tiny_pairs = value; }
 #ifdef QGX_AB
     else if (!strcmp(name, "pair_lp")) g->opt_pair_lp = value;
 #endif

@@ -72,6 +72,33 @@ def test_split_f16_is_float32_class(kind, N, B):
         assert errs['default'] < 2e-5
 
 
+@pytest.mark.parametrize('kind,B', [('gan', 1), ('vae', 3), ('gz', 5)])
+def test_single_member_strips_are_float32_class(kind, B):
+    """Tiny ensembles at 64 x 64 (the split-K path of a single member, BASELINE configs[1]): layers (3, 4), (5, 6) and (7, 8)
+    each run as ONE fused launch on 2-row strips (option `tiny_pairs`, bits 2 / 1 / 0; default all) instead of split-K +
+    combine + four layer launches + the VALU last layer.  Every combination stays in the float32 error class against the
+    float64 evaluation of the reference's arithmetic (cnn_tools.py:79-98,125-176), and within 1e-5 of the unfused path."""
+    gen = _gpu_generator(kind)
+    nets = _oracle_nets(kind)
+    rs = np.random.RandomState(40 + B)
+    x = rs.randn(B, nets[0].n_in, 64, 64).astype('float32')
+    x[:, :2] *= 1.5
+    xd = torch.as_tensor(x, device='cuda')
+    for inet, w in enumerate(nets):
+        truth = gen_ref.cnn_forward(w, x, dtype='float64')
+        err_ref = _maxrel(gen_ref.cnn_forward(w, x), truth)
+        ys = {}
+        for tp in (0, 1, 2, 4, 7):
+            gen.set_option('tiny_pairs', tp)
+            ys[tp] = gen.cnn_forward(xd, inet).cpu().numpy()
+            assert gen.layer2_kernel(B, 64, inet) == 2          # the split-K path is the one in use
+            err = _maxrel(ys[tp], truth)
+            assert err < 4 * err_ref + 1e-7 and err < 2e-5, (tp, err, err_ref)
+            assert _maxrel(ys[tp], ys[0]) < 1e-5
+        assert not np.array_equal(ys[7], ys[0])                  # (the strips are another order of summation: they did run)
+        gen.set_option('tiny_pairs', 7)
+
+
 @pytest.mark.parametrize('kind', ['gan', 'vae', 'gz'])
 def test_split_f16_golden_vectors(kind):
     """the reference's own outputs (Parameterization.__call__, tests/golden/generator.npz) at the
