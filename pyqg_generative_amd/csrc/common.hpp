@@ -220,6 +220,7 @@ struct qgx_model {
     hipStream_t adv_stream[2] = {nullptr, nullptr};
     hipEvent_t adv_event[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int adv_slot = 0;
+    bool is_half = false;                        // a half-ensemble view of a model stepped as two halves on two streams (model.hip::qgx_step)
     hipStream_t sub_stream[2] = {nullptr, nullptr};
     hipEvent_t sub_event[3] = {nullptr, nullptr, nullptr};
 };

@@ -65,7 +65,7 @@ static int model_step_once(qgx_model *m, bool has_S, const double *S, double wei
         QGX_HIP(hipStreamWaitEvent(st, m->adv_event[m->adv_slot][1], 0));
         rc = small_step(m->d, m->opts, a, st, 2);
     } else if (m->small && has_S && m->sib_flag && m->opts.siblings != 0 && small_layer_split(m->d, m->opts) &&
-               (m->opts.siblings >= 1 || 4 * m->B <= 256)) {    // while all four workgroups of every member are resident at once
+               (m->opts.siblings >= 1 || 4 * m->B * (m->is_half ? 2 : 1) <= 256)) {   // (two halves run side by side: both must fit)    // while all four workgroups of every member are resident at once
         // the forcing's transform on a workgroup of its own beside the inversion / advection chain (k_step_small PART 3)
         a.sib_flag = m->sib_flag;
         a.sib_epoch = ++m->sib_epoch;
@@ -681,7 +681,11 @@ static int step_core(qgx_model *m, int nsteps, const qgx_param *p, int refresh_d
 // members +6.5 / +4 / +4 / +11 / +1 % (before the 96 x 96 tile shapes were chosen by quantisation: +20 / . / +11.5 / +20 / +9 %); 64 x 64 with 16 / 32 / 48 / 64 / 128 members -1 / 0 / +19 / 0 / +0.4 %; 48 x 48 with 32 /
 // 64 members -25 / +27 %; 32 x 32 with 64 members -5 %: on the smaller grids the sign follows the tile-count quantisation of the
 // halves against the whole, not a rule, so the automatic choice is the 96 x 96 grid (16 ... 64 members) only and option
-// "streams" = 2 asks for it elsewhere.
+// "streams" = 2 asks for it elsewhere.  Round 4 (bench_tools/halves_sizes.py): at 64 x 64 / 128 members the two-halves step
+// takes 635 ... 639 us on every box met, the one-stream step 637 us on a fast box and 662 ... 665 us on slow ones (the boxes
+// differ in the clock the f16 MFMA kernels sustain; interleaving the halves' memory-bound and MFMA-bound kernels evens that
+// out): +4 % where the box is slow, nothing where it is fast.  Not the default there: layer 2 of a half runs beside other
+// kernels, so the bench's live roofline of that kernel would describe the mix, not the kernel.
 static bool step_in_halves(const qgx_model *m, const qgx_param *p) {
     if (m->opts.streams == 1 || !m->small || (m->B & 1) || !p || !p->gen || p->z_external_dev) return false;
     if (m->opts.streams == 2) return true;
@@ -736,6 +740,7 @@ extern "C" int qgx_step(qgx_model *m, int nsteps, const qgx_param *p, int refres
         }
         k.sub_stream[0] = k.sub_stream[1] = nullptr;
         k.adv_slot = c;
+        k.is_half = true;
         if (k.sib_flag) k.sib_flag += b0 * 4;          // (a half owns the flag words and the placement words of its members: 4 per member)
         pp[c].member_offset = p->member_offset + b0;
     }
